@@ -1,0 +1,317 @@
+"""
+The reference's known-answer tests (modules/unit_tests.py, catalogued in SURVEY.md
+Appendix C) restated as recipes over an implementation object `impl`.
+
+`impl` offers the reference's function names on one column of plain 1-D float64
+arrays and returns dicts (oracle/parcel_oracle.py is such an object; the product's
+xarray_parcel_amd.numpy_api is another).  Inputs and expected values come from
+tests/golden/kat_vectors.json (extracted from the reference's test file by
+tests/golden/make_kat_vectors.py); nothing here reads /root/reference.
+
+Every KAT assumes the *exact* moist adiabat (the reference runs them with
+parcel.moist_lapse monkey-patched to MetPy's ODE, parcel_functions_demo.ipynb
+cell 33); the four test_moist_lapse* recipes are also run in table mode at the
+looser decimals of unit_tests.py:106-112.
+"""
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(_HERE, 'golden', 'kat_vectors.json')) as _f:
+    KAT = json.load(_f)
+
+
+def arr(x):
+    if isinstance(x, list):
+        return np.array([np.nan if v is None else v for v in x], dtype=np.float64)
+    return np.nan if x is None else float(x)
+
+
+def inputs(name):
+    return {k: arr(v) for k, v in KAT[name]['inputs'].items()}
+
+
+def expected(name):
+    return [(e['what'], arr(e['value']), e['decimal']) for e in KAT[name]['expected']]
+
+
+def check(name, actual, loosen=None):
+    """assert_almost_equal semantics: |a-e| < 1.5 * 10**-decimal; NaN must match NaN."""
+    for what, exp, dec in expected(name):
+        if loosen is not None:
+            dec = min(dec, loosen)
+        assert what in actual, f'{name}: recipe produced no value for {what}'
+        a = np.asarray(actual[what], dtype=np.float64)
+        e = np.asarray(exp, dtype=np.float64)
+        assert a.shape == e.shape or a.size == e.size, f'{name}:{what} shape {a.shape} vs {e.shape}'
+        a = a.reshape(e.shape)
+        nan_a, nan_e = np.isnan(a), np.isnan(e)
+        assert np.array_equal(nan_a, nan_e), f'{name}:{what} NaN pattern {a} vs {e}'
+        if (~nan_e).any():
+            err = np.max(np.abs(a[~nan_e] - e[~nan_e]))
+            assert err < 1.5 * 10.0 ** (-dec), f'{name}:{what} |diff|={err:.3e} at decimal={dec}: {a} vs {e}'
+
+
+# -- recipe building blocks -------------------------------------------------------
+def _sfc_profile_lfc_el(impl, i, lcl_interp='linear', parcel=None):
+    p, t, td = i['levels'], i['temperatures'], i['dewpoints']
+    if parcel is None:
+        parcel = (p[0], t[0], td[0])
+    prof = impl.parcel_profile_with_lcl(p, t, td, parcel[0], parcel[1], parcel[2],
+                                        lcl_interp=lcl_interp)
+    le = impl.lfc_el(prof['pressure'], prof['temperature'], prof['environment_temperature'],
+                     prof['lcl_pressure'], prof['lcl_temperature'])
+    return prof, le
+
+
+def _nolcl_profile_lfc_el(impl, i, parcel=None, add=0.0):
+    p, t, td = i['levels'], i['temperatures'], i['dewpoints']
+    if parcel is None:
+        parcel = (p[0], t[0], td[0])
+    prof = impl.parcel_profile(p, parcel[0], parcel[1], parcel[2])
+    prof = dict(prof)
+    prof['temperature'] = prof['temperature'] + add
+    prof['environment_temperature'] = t
+    le = impl.lfc_el(prof['pressure'], prof['temperature'], prof['environment_temperature'],
+                     prof['lcl_pressure'], prof['lcl_temperature'])
+    return prof, le
+
+
+def _lfc(le, prefix):
+    return {prefix + '.lfc_pressure': le['lfc_pressure'], prefix + '.lfc_temperature': le['lfc_temperature'],
+            prefix + '.el_pressure': le['el_pressure'], prefix + '.el_temperature': le['el_temperature']}
+
+
+MP = dict(virtual_temperature_correction=False, lcl_interp='linear')
+
+
+def _r_lfc_sfc(prefix, **kw):
+    def r(impl, i):
+        _, le = _sfc_profile_lfc_el(impl, i, **kw)
+        return _lfc(le, prefix)
+    return r
+
+
+def _r_lfc_mixed(prefix):
+    def r(impl, i):
+        m = impl.mixed_parcel(i['levels'], i['temperatures'], i['dewpoints'])
+        _, le = _sfc_profile_lfc_el(impl, i, parcel=(m['pressure'], m['temperature'], m['dewpoint']))
+        return _lfc(le, prefix)
+    return r
+
+
+def _r_lfc_intersection(impl, i):
+    m = impl.mixed_parcel(i['levels'], i['temperatures'], i['dewpoints'])
+    _, le = _nolcl_profile_lfc_el(impl, i, parcel=(m['pressure'], m['temperature'], m['dewpoint']))
+    return _lfc(le, 'lfc')
+
+
+def _r_cape_cin_nolcl(add=0.0):
+    def r(impl, i):
+        prof, le = _nolcl_profile_lfc_el(impl, i, add=add)
+        cc = impl.cape_cin_base(i['levels'], i['temperatures'], le['lfc_pressure'], le['el_pressure'],
+                                prof['temperature'])
+        return {'cape_cin.cape': cc['cape'], 'cape_cin.cin': cc['cin']}
+    return r
+
+
+def _r_sb(**kw):
+    def r(impl, i):
+        cc, _ = impl.surface_based_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **kw)
+        return {'cape_cin.cape': cc['cape'], 'cape_cin.cin': cc['cin']}
+    return r
+
+
+def _r_mu(**kw):
+    def r(impl, i):
+        cc, _, _ = impl.most_unstable_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **kw)
+        return {'cape_cin.cape': cc['cape'], 'cape_cin.cin': cc['cin']}
+    return r
+
+
+def _r_sensitive(**kw):
+    def r(impl, i):
+        _, le = _sfc_profile_lfc_el(impl, i)
+        out = _lfc(le, 'lfc')
+        cc, _ = impl.surface_based_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **kw)
+        out.update({'cape_cin.cape': cc['cape'], 'cape_cin.cin': cc['cin']})
+        return out
+    return r
+
+
+def _r_nans(**kw):
+    def r(impl, i):
+        prof, le = _nolcl_profile_lfc_el(impl, i)
+        base = impl.cape_cin_base(i['levels'], i['temperatures'], le['lfc_pressure'], le['el_pressure'],
+                                  prof['temperature'])
+        surf, _ = impl.surface_based_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **kw)
+        mu, _, _ = impl.most_unstable_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **kw)
+        return {'lfc.lfc_pressure': le['lfc_pressure'],
+                'cape_cin_base.cape': base['cape'], 'cape_cin_base.cin': base['cin'],
+                'cape_cin_surf.cape': surf['cape'], 'cape_cin_surf.cin': surf['cin'],
+                'cape_cin_unstable.cape': mu['cape'], 'cape_cin_unstable.cin': mu['cin']}
+    return r
+
+
+def _r_dry(t0):
+    return lambda impl, i: {'temps': impl.dry_lapse(i['levels'], t0)}
+
+
+def _r_moist(t0, pref=None):
+    return lambda impl, i: {'temp': impl.moist_lapse(i['levels'], t0, pref)}
+
+
+def _r_profile(impl, i):
+    prof = impl.parcel_profile(i['levels'], i['parcel_pressure'], i['parcel_temperature'],
+                               i['parcel_dewpoint'])
+    return {'prof.temperature': prof['temperature']}
+
+
+def _r_profile_below(impl, i):
+    prof = impl.parcel_profile(i['pressure'], i['pressure'][0], i['parcel_temperature'],
+                               i['parcel_dewpoint'])
+    return {'profile.temperature': prof['temperature']}
+
+
+def _r_profile_lcl(impl, i):
+    prof = impl.parcel_profile(i['p'], i['parcel_pressure'], i['parcel_temperature'],
+                               i['parcel_dewpoint'])
+    prof = impl.add_lcl_to_profile(prof, environment={'temperature': i['t'], 'pressure': prof['pressure']},
+                                   interpolator='linear')
+    return {'prof.pressure': prof['pressure'], 'prof.environment_temperature': prof['environment_temperature'],
+            'prof.temperature': prof['temperature']}
+
+
+def _r_lcl(impl, i):
+    l = impl.lcl(i['parcel_pressure'], i['parcel_temperature'], i['parcel_dewpoint'])
+    return {'lcl.lcl_pressure': l['lcl_pressure'], 'lcl.lcl_temperature': l['lcl_temperature']}
+
+
+def _r_lcl_columns(pk, tk, dk):
+    def r(impl, i):
+        ls = [impl.lcl(p, t, d) for p, t, d in zip(i[pk], i[tk], i[dk])]
+        return {'lcl.lcl_pressure': np.array([l['lcl_pressure'] for l in ls]),
+                'lcl.lcl_temperature': np.array([l['lcl_temperature'] for l in ls])}
+    return r
+
+
+def _r_lcl_conv(impl, i):
+    l = impl.lcl(i['pressure'][0], i['temperatures'][0], i['dewpoints'][0])
+    return {'lcl.lcl_pressure': l['lcl_pressure']}
+
+
+def _r_mu_parcel(impl, i):
+    m = impl.most_unstable_parcel(i['levels'], i['temperatures'], i['dewpoints'], depth=100)
+    return {'ret.pressure': m['pressure'], 'ret.temperature': m['temperature'], 'ret.dewpoint': m['dewpoint']}
+
+
+def _r_mixed_parcel(impl, i):
+    m = impl.mixed_parcel(i['levels'], i['temperatures'], i['dewpoints'], depth=250)
+    return {'mixed.pressure': m['pressure'], 'mixed.temperature': m['temperature'], 'mixed.dewpoint': m['dewpoint']}
+
+
+def _r_mixed_layer(impl, i):
+    m = impl.mixed_layer({'pressure': i['pressure'], 'temperature': i['temperature']}, depth=250)
+    return {'mixed.temperature': m['temperature']}
+
+
+def _r_ml_cape(impl, i):
+    cc, _, _ = impl.mixed_layer_cape_cin(i['levels'], i['temperatures'], i['dewpoints'], **MP)
+    return {'cape_cin.cape': cc['cape'], 'cape_cin.cin': cc['cin']}
+
+
+def _r_lifted_index(impl, i):
+    prof = dict(impl.parcel_profile(i['pressure'], i['pressure'][0], i['temperature'][0], i['dewpoint'][0]))
+    prof['environment_temperature'] = i['temperature']
+    return {'li.lifted_index': impl.lifted_index(prof)}
+
+
+def _r_wet_bulb(pk, tk, dk):
+    return lambda impl, i: {'val': impl.wet_bulb_temperature(i[pk], i[tk], i[dk])}
+
+
+def _r_insert_level(impl, i):
+    # the two inline columns of unit_tests.py:1388-1411
+    res_p, res_t = [], []
+    for lev_p, lev_t in ((1000.0, 1.5), (600.0, 2.0)):
+        r = impl.insert_level({'pressure': np.array([1000.0, 900.0, 800.0, 700.0]),
+                               'temperature': np.array([1.0, 1.0, 1.0, 1.0])},
+                              {'pressure': lev_p, 'temperature': lev_t})
+        res_p.append(r['pressure'])
+        res_t.append(r['temperature'])
+    return {'res.pressure': np.concatenate(res_p), 'res.temperature': np.concatenate(res_t)}
+
+
+RECIPES = {
+    'test_dry_lapse': _r_dry(303.15),
+    'test_dry_lapse_2_levels': _r_dry(293.0),
+    'test_moist_lapse': _r_moist(293.0),
+    'test_moist_lapse_ref_pres': _r_moist(293.0, 1000.0),
+    'test_moist_lapse_scalar': _r_moist(293.0, 1000.0),
+    'test_moist_lapse_uniform': _r_moist(293.15),
+    'test_parcel_profile': _r_profile,
+    'test_parcel_profile_lcl': _r_profile_lcl,
+    'test_parcel_profile_saturated': _r_profile,
+    'test_parcel_profile_below_lcl': _r_profile_below,
+    'test_lcl': _r_lcl,
+    'test_lcl_nans': _r_lcl_columns('p', 't', 'd'),
+    'test_lcl_convergence_issue': _r_lcl_conv,
+    'test_lcl_grid_surface_lcls': _r_lcl_columns('pressure', 'temperature', 'dewpoint'),
+    'test_lfc_basic': _r_lfc_sfc('lfc'),
+    'test_lfc_ml': _r_lfc_mixed('lfc'),
+    'test_lfc_ml2': _r_lfc_mixed('lfc'),
+    'test_lfc_intersection': _r_lfc_intersection,
+    'test_no_lfc': _r_lfc_sfc('lfc'),
+    'test_lfc_inversion': _r_lfc_sfc('lfc'),
+    'test_lfc_equals_lcl': _r_lfc_sfc('lfc'),
+    'test_sensitive_sounding': _r_sensitive(),
+    'test_sensitive_sounding_mp': _r_sensitive(**MP),
+    'test_lfc_sfc_precision': _r_lfc_sfc('lfc'),
+    'test_lfc_pos_area_below_lcl': _r_lfc_sfc('lfc'),
+    'test_el': _r_lfc_sfc('el'),
+    'test_el_ml': _r_lfc_mixed('el'),
+    'test_no_el': _r_lfc_sfc('el'),
+    'test_no_el_multi_crossing': _r_lfc_sfc('el'),
+    'test_lfc_and_el_below_lcl': _r_lfc_sfc('el'),
+    'test_el_lfc_equals_lcl': _r_lfc_sfc('el'),
+    'test_el_small_surface_instability': _r_lfc_sfc('el'),
+    'test_no_el_parcel_colder': _r_lfc_sfc('el'),
+    'test_el_below_lcl': _r_lfc_sfc('el'),
+    'test_cape_cin': _r_cape_cin_nolcl(),
+    'test_cape_cin_no_el': _r_cape_cin_nolcl(),
+    'test_cape_cin_no_lfc': _r_cape_cin_nolcl(),
+    'test_cape_cin_custom_profile': _r_cape_cin_nolcl(add=5.0),
+    'test_most_unstable_parcel': _r_mu_parcel,
+    'test_surface_based_cape_cin': _r_sb(),
+    'test_surface_based_cape_cin_mp': _r_sb(**MP),
+    'test_profile_with_nans': _r_nans(),
+    'test_profile_with_nans_mp': _r_nans(**MP),
+    'test_most_unstable_cape_cin_surface': _r_mu(),
+    'test_most_unstable_cape_cin_surface_mp': _r_mu(**MP),
+    'test_profile_with_lcl_in_levels': _r_mu(),
+    'test_profile_with_lcl_in_levels_mp': _r_mu(**MP),
+    'test_mixed_parcel': _r_mixed_parcel,
+    'test_mixed_layer': _r_mixed_layer,
+    'test_mixed_layer_cape_cin': _r_ml_cape,
+    'test_multiple_lfcs_el_simple': _r_lfc_sfc('lfc_el'),
+    'test_lfc_not_below_lcl': _r_lfc_sfc('lfc_el', lcl_interp='log'),
+    'test_cape_cin_value_error': _r_sb(**MP),
+    'test_lcl_grid_surface_lcls_': None,
+    'test_lifted_index': _r_lifted_index,
+    'test_wet_bulb_temperature': _r_wet_bulb('levels', 'temp', 'dewp'),
+    'test_wet_bulb_temperature_saturated': _r_wet_bulb('levels', 'temp', 'dewp'),
+    'test_wet_bulb_temperature_1d': _r_wet_bulb('pressures', 'temperatures', 'dewpoints'),
+    'test_insert_level': _r_insert_level,
+}
+RECIPES = {k: v for k, v in RECIPES.items() if v is not None}
+
+# Disabled in the reference's own run_all_tests (unit_tests.py:31): MetPy's block-wide
+# LCL stop rule; it passes with a per-column LCL and is kept.
+MOIST_LAPSE_KATS = ['test_moist_lapse', 'test_moist_lapse_ref_pres', 'test_moist_lapse_scalar',
+                    'test_moist_lapse_uniform']
+
+
+def run(name, impl, loosen=None):
+    check(name, RECIPES[name](impl, inputs(name)), loosen=loosen)
