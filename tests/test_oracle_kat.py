@@ -10,7 +10,10 @@ from tests import kat_recipes as kr
 # error of MetPy's LSODA solve (atol 1e-7 / rtol 1.5e-8): LSODA gives 2007.0413, a tight DOP853
 # solve of the same ODE gives 2007.0493 and the RK4 spec 2007.0495.  In RK4 mode the KAT is
 # therefore held to 2 decimals (|diff| < 0.015 J/kg); every other KAT keeps its own decimals.
-RK4_LOOSEN = {'test_cape_cin_value_error': 2}
+# test_el asserts EL = 471.83286 hPa to 3 decimals on a 700 -> 269 hPa leg with a very shallow
+# crossing: LSODA gives 471.8327, tight DOP853 471.8290, the RK4 spec 471.8275 (its parcel
+# temperature at 269 hPa is 2.3e-5 K from the tight solve, LSODA's is 2.9e-5 K).  Held to 2 decimals.
+RK4_LOOSEN = {'test_cape_cin_value_error': 2, 'test_el': 2}
 
 
 @pytest.fixture(autouse=True)
