@@ -1,0 +1,44 @@
+"""The C oracle (oracle/c/xp_oracle.c) against (a) the reference's KATs and (b) the Python oracle
+on seeded synthetic columns incl. NaNs.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import parcel_oracle as po
+from tests import kat_recipes as kr
+from tests.test_oracle_kat import RK4_LOOSEN
+from xarray_parcel_amd import synth
+
+
+@pytest.mark.parametrize('name', kr.applicable(co))
+def test_kat_c_oracle(name):
+    co.set_moist_lapse('rk4')
+    kr.run(name, co, loosen=RK4_LOOSEN.get(name))
+
+
+MODES = [dict(), dict(virtual_temperature_correction=False, lcl_interp='linear'),
+         dict(pos_cape_neg_cin=False), dict(post_zero_cin=True, lcl_interp='linear')]
+
+
+@pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
+@pytest.mark.parametrize('mode', range(len(MODES)))
+def test_c_vs_python_oracle(parcel, mode):
+    kw = MODES[mode]
+    p, t, td = synth.columns(nlev=40, ncol=60, seed=100 + mode, nan_fraction=0.1, dtype=np.float64)
+    got = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4', **kw)
+    fn = {'surface': po.surface_based_cape_cin, 'most_unstable': po.most_unstable_cape_cin,
+          'mixed_layer': po.mixed_layer_cape_cin}[parcel]
+    po.set_moist_lapse('rk4')
+    try:
+        for c in range(p.shape[1]):
+            res = fn(p[:, c], t[:, c], td[:, c], per_column_lcl=True, **kw)
+            cc, prof = res[0], res[1]
+            for k in ('cape', 'cin'):
+                assert np.isclose(got[k][c], cc[k], rtol=1e-9, atol=1e-9), (c, k, got[k][c], cc[k])
+            for k in ('lcl_pressure', 'lfc_pressure', 'lfc_temperature', 'el_pressure', 'el_temperature'):
+                a, b = got[k][c], prof[k]
+                assert (np.isnan(a) and np.isnan(b)) or np.isclose(a, b, rtol=1e-10, atol=1e-9), (c, k, a, b)
+            assert got['lfc_index'][c] == prof['lfc_index'], (c, got['lfc_index'][c], prof['lfc_index'])
+            assert got['el_index'][c] == prof['el_index'], (c, got['el_index'][c], prof['el_index'])
+    finally:
+        po.set_moist_lapse('ode')
