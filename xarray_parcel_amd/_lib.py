@@ -1,0 +1,127 @@
+"""ctypes binding of libxparcel.so (include/xparcel.h).  No CPU fallback: if the library is missing
+or no MI355X is visible, calls raise."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libxparcel.so')
+SRC_DIR = os.path.join(_HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include', 'xparcel.h')
+
+XP_F32, XP_F64 = 0, 1
+XP_MEM_HOST, XP_MEM_DEVICE = 0, 1
+PARCEL = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
+MOIST = {'exact': 0, 'table': 1}
+LCL_INTERP = {'linear': 0, 'log': 1}
+ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE = 1, 2, 4
+
+# every symbol include/xparcel.h declares
+SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
+           'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
+           'xp_mixed_layer', 'xp_last_error')
+
+
+class View(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('dtype', C.c_int32), ('mem', C.c_int32), ('nlev', C.c_int64),
+                ('ncol', C.c_int64), ('lev_stride', C.c_int64), ('col_stride', C.c_int64)]
+
+
+class Parcel(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('reserved', C.c_int32), ('depth', C.c_double), ('pressure', C.c_void_p),
+                ('temperature', C.c_void_p), ('dewpoint', C.c_void_p)]
+
+
+class Opts(C.Structure):
+    _fields_ = [('virtual_temperature_correction', C.c_int32), ('lcl_interp', C.c_int32),
+                ('pos_cape_neg_cin', C.c_int32), ('post_zero_cin', C.c_int32), ('moist_mode', C.c_int32),
+                ('compute', C.c_int32), ('reserved', C.c_int32 * 2)]
+
+
+SCALAR_F = ('cape', 'cin', 'lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature', 'lfc_pressure',
+            'lfc_temperature', 'el_pressure', 'el_temperature')
+SCALAR_I = ('lfc_index', 'el_index', 'status', 'parcel_index')
+SCALAR_P = ('parcel_pressure', 'parcel_temperature', 'parcel_dewpoint')
+
+
+class ScalarsOut(C.Structure):
+    _fields_ = ([(k, C.c_void_p) for k in SCALAR_F] + [(k, C.c_void_p) for k in SCALAR_I] +
+                [(k, C.c_void_p) for k in SCALAR_P] + [('dtype', C.c_int32), ('mem', C.c_int32)])
+
+
+PROFILE_VARS = ('pressure', 'temperature', 'virtual_temperature', 'environment_temperature',
+                'environment_virtual_temperature', 'environment_dewpoint')
+
+
+class ProfileOut(C.Structure):
+    _fields_ = ([(k, C.c_void_p) for k in PROFILE_VARS] +
+                [('dtype', C.c_int32), ('mem', C.c_int32), ('nlev_out', C.c_int64), ('lev_stride', C.c_int64),
+                 ('col_stride', C.c_int64)])
+
+
+class Tables(C.Structure):
+    _fields_ = [('n_pressure', C.c_int64), ('n_temperature', C.c_int64), ('n_adiabat', C.c_int64),
+                ('p_max', C.c_double), ('p_step', C.c_double), ('t_min', C.c_double), ('t_step', C.c_double),
+                ('index', C.c_void_p), ('adiabats', C.c_void_p)]
+
+
+class XParcelError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libxparcel error {code}: {msg}')
+        self.code = code
+
+
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared']
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [INCLUDE]
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB_PATH, os.path.join(SRC_DIR, 'xparcel.hip')]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+_inited_device = None
+
+
+def load():
+    """dlopen the library (no GPU needed for this)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                  '(there is no CPU fallback)')
+            _lib = C.CDLL(LIB_PATH)
+            _lib.xp_last_error.restype = C.c_char_p
+            for s in SYMBOLS:
+                getattr(_lib, s)
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise XParcelError(rc, load().xp_last_error().decode())
+
+
+def init(device=None):
+    """xp_init on the given (or torch-current, or 0) device."""
+    global _inited_device
+    lib = load()
+    if device is None:
+        device = _inited_device if _inited_device is not None else int(os.environ.get('LOCAL_RANK', '0'))
+    if _inited_device != device:
+        check(lib.xp_init(int(device)))
+        _inited_device = device
+    return lib

@@ -1,0 +1,267 @@
+// xp_device.hpp -- device-side building blocks of libxparcel (gfx950).
+//
+// One thread owns one atmospheric column and streams it bottom-up exactly once.
+// The reference (traupach/xarray_parcel modules/parcel_functions.py, "pf.py") instead
+// materialises an (N+1)-level profile with the LCL inserted and runs ~100 full-array
+// passes over it; here the LCL is a *virtual node* emitted when the scan passes
+// p_lcl, and everything lfc_el (pf.py:1066-1198) and cape_cin_base (pf.py:1291-1392)
+// need is carried in registers as running extrema and prefix sums:
+//
+//   CAPE = Rd * (PosArea(up to EL) - PosArea(up to LFC)),  CIN = Rd * NegArea(up to LFC)
+//
+// where the LFC is either the first qualifying increasing crossing or the LCL
+// (fall-backs of pf.py:1161-1185) and the EL is the last decreasing crossing or the
+// column top -- both only known at the end, hence the snapshots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xp {
+
+// MetPy 1.4.1 constants (the reference's un-vendored dependency)
+constexpr double RD = 287.04749097718457;
+constexpr double EPS = 0.6219569100577033;
+constexpr double KAPPA = 2.0 / 7.0;
+constexpr double CP_D = RD / KAPPA;
+constexpr double LV = 2.50084e6;
+constexpr double VT_EPS = 0.608;      // hard-coded in pf.py:782
+constexpr double RK4_H_MAX = 0.1;     // exact-mode step bound in ln p (shared with the oracle)
+
+#define XP_DEV __device__ __forceinline__
+
+XP_DEV double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+XP_DEV bool isnan_(double x) { return x != x; }
+
+// ---- thermodynamics ---------------------------------------------------------------------
+XP_DEV double sat_vapor_pressure(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
+XP_DEV double dewpoint_of_e(double e) { double v = log(e / 6.112); return 273.15 + 243.5 * v / (17.67 - v); }
+XP_DEV double mix_of_e(double e, double p) { return EPS * e / (p - e); }
+XP_DEV double sat_mix(double p, double t) { return mix_of_e(sat_vapor_pressure(t), p); }
+XP_DEV double vapor_pressure(double p, double w) { return p * w / (EPS + w); }
+// pf.py:684-710: relative humidity (from dewpoint) times saturation mixing ratio
+XP_DEV double mixing_ratio(double t, double td, double p) {
+    double est = sat_vapor_pressure(t);
+    return (sat_vapor_pressure(td) / est) * mix_of_e(est, p);
+}
+XP_DEV double virt(double t, double w) { return t * (1.0 + VT_EPS * w); }
+// Bolton (1980) eq. 39 (metpy.calc.equivalent_potential_temperature, pf.py:123)
+XP_DEV double theta_e(double p, double t, double td) {
+    double e = sat_vapor_pressure(td), r = mix_of_e(e, p);
+    double tl = 56.0 + 1.0 / (1.0 / (td - 56.0) + log(t / td) / 800.0);
+    double thl = t / pow((p - e) / 1000.0, KAPPA) * pow(t / tl, 0.28 * r);
+    return thl * exp(r * (1.0 + 0.448 * r) * (3036.0 / tl - 1.78));
+}
+
+// ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
+XP_DEV double lcl_iter(double p, double p0, double w, double t) {
+    double td = dewpoint_of_e(vapor_pressure(p, w));
+    return p0 * pow(td / t, 1.0 / KAPPA);
+}
+struct Lcl { double p, t, tv; int not_converged; };
+XP_DEV Lcl lcl(double p_start, double t, double td) {
+    Lcl r;
+    r.not_converged = 0;
+    if (isnan_(p_start) || isnan_(t) || isnan_(td)) { r.p = r.t = r.tv = qnan(); return r; }   // pf.py:627-634, 680
+    double w = mix_of_e(sat_vapor_pressure(td), p_start);
+    double p0 = p_start, p = qnan();
+    bool conv = false;
+    for (int it = 0; it < 50; ++it) {
+        double p1 = lcl_iter(p0, p_start, w, t);
+        double p2 = lcl_iter(p1, p_start, w, t);
+        double d = p2 - 2.0 * p1 + p0;
+        p = (d != 0.0) ? p0 - (p1 - p0) * (p1 - p0) / d : p2;
+        double rel = (p0 != 0.0) ? (p - p0) / p0 : p;
+        if (fabs(rel) < 1e-5) { conv = true; break; }
+        p0 = p;
+    }
+    if (!conv) { p = qnan(); r.not_converged = 1; }
+    if (fabs(p - p_start) <= 1e-8 + 1e-5 * fabs(p_start)) p = p_start;    // np.isclose snap (MetPy issue #1187)
+    r.p = p;
+    r.t = dewpoint_of_e(vapor_pressure(p, w));
+    r.tv = virt(r.t, mix_of_e(sat_vapor_pressure(r.t), p));                // RH = 1 at the LCL (pf.py:653-657)
+    return r;
+}
+
+// ---- moist adiabat ------------------------------------------------------------------------
+// dT/dln p of MetPy's pseudo-adiabat, one division (same grouping as the oracle)
+XP_DEV double dt_dlnp(double p, double t) {
+    double e = sat_vapor_pressure(t), pe = p - e;
+    double num = RD * t * pe + LV * EPS * e;
+    double den = CP_D * RD * t * t * pe + LV * LV * EPS * EPS * e;
+    return RD * t * t * num / den;
+}
+
+struct Tables {               // reference-format lookup tables resident in HBM (pf.py:447-523)
+    const uint16_t *index;    // [n_p][n_t], 0 = NaN
+    const float *adiabats;    // [n_ad][n_p] ascending pressure
+    int64_t n_p, n_t;
+    double p_max, p_step, t_min, t_step;
+};
+
+// Parcel temperature above the LCL.  Exact mode marches RK4 from node to node; table mode picks the
+// adiabat row once (nearest neighbour, pf.py:554-556) and interpolates linearly in p (pf.py:585-592).
+struct Moist {
+    double x, p, t;           // exact mode: current point on the adiabat (ln p, p, T)
+    const float *row;         // table mode: selected adiabat, nullptr = NaN
+    bool table, dead;
+
+    XP_DEV void start(double p_ref, double x_ref, double t_ref, bool table_mode, const Tables &tb) {
+        x = x_ref; p = p_ref; t = t_ref; table = table_mode; row = nullptr;
+        dead = isnan_(p_ref) || isnan_(t_ref);
+        if (table_mode && !dead) {
+            double fi = (tb.p_max - p_ref) / tb.p_step, fj = (t_ref - tb.t_min) / tb.t_step;
+            double i0 = floor(fi), j0 = floor(fj);
+            // pandas nearest on a DEcreasing index keeps the left (higher-pressure) label on ties,
+            // on an increasing index the right one
+            int64_t ip = (int64_t)(((i0 + 1.0) - fi < fi - i0) ? i0 + 1.0 : i0);
+            int64_t jt = (int64_t)(((j0 + 1.0) - fj <= fj - j0) ? j0 + 1.0 : j0);
+            ip = ip < 0 ? 0 : (ip > tb.n_p - 1 ? tb.n_p - 1 : ip);
+            jt = jt < 0 ? 0 : (jt > tb.n_t - 1 ? tb.n_t - 1 : jt);
+            uint16_t a = tb.index[ip * tb.n_t + jt];
+            if (a) row = tb.adiabats + (int64_t)(a - 1) * tb.n_p;
+        }
+    }
+    // temperature of the adiabat at pressure pk (ln pk = xk); levels must come in order of
+    // increasing distance from the start point (pressure decreasing upwards)
+    XP_DEV double at(double pk, double xk, const Tables &tb) {
+        if (dead || isnan_(pk)) return qnan();
+        if (table) {
+            double p_min = tb.p_max - (double)(tb.n_p - 1) * tb.p_step;
+            if (row == nullptr || pk < p_min || pk > tb.p_max) return qnan();        // pf.py:598-600
+            double f = (pk - p_min) / tb.p_step;
+            int64_t lo = (int64_t)floor(f);
+            if (lo >= tb.n_p - 1) return (double)row[tb.n_p - 1];
+            double xlo = p_min + (double)lo * tb.p_step, xhi = p_min + (double)(lo + 1) * tb.p_step;
+            double ylo = (double)row[lo], yhi = (double)row[lo + 1];
+            return (yhi - ylo) / (xhi - xlo) * (pk - xlo) + ylo;                       // np.interp
+        }
+        if (xk != x) {
+            double dx = xk - x;
+            int ns = (int)ceil(fabs(dx) / RK4_H_MAX - 1e-12);
+            ns = ns < 1 ? 1 : ns;
+            double h = dx / (double)ns;
+            double rh = exp(0.5 * h);
+            double ps = p;
+            for (int s = 0; s < ns; ++s) {
+                double pm = ps * rh;
+                double pe = (s == ns - 1) ? pk : pm * rh;
+                double k1 = dt_dlnp(ps, t);
+                double k2 = dt_dlnp(pm, t + 0.5 * h * k1);
+                double k3 = dt_dlnp(pm, t + 0.5 * h * k2);
+                double k4 = dt_dlnp(pe, t + h * k3);
+                t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+                ps = pe;
+            }
+            x = xk; p = pk;
+        }
+        return t;
+    }
+};
+
+// ---- the streaming LFC / EL / CAPE / CIN state machine ------------------------------------------
+// Nodes are the levels of the LCL-augmented profile in order; feed them with node().
+struct Scan {
+    // configuration
+    double p_lcl;
+    bool pos_neg;
+    // previous node
+    double Xp, yp, parp;
+    int j;                 // nodes seen so far
+    bool use_all;          // env[0] != par[0] (pf.py:1117-1120)
+    // prefix sums and snapshots
+    double cape, cin, cape_lcl, cin_lcl, cape_lfc, cin_lfc, cape_el;
+    // crossings
+    double lfc_p, lfc_t, el_p, el_t;
+    int lfc_idx, el_idx;
+    bool any_inc, pos_parcel, env_any;
+    // top of column where both temperatures exist (pf.py:1143-1147)
+    double top_p, top_par, top_env, min_p;
+
+    XP_DEV void init(double p_lcl_, bool pos_neg_) {
+        p_lcl = p_lcl_; pos_neg = pos_neg_;
+        Xp = yp = parp = qnan(); j = 0; use_all = true;
+        cape = cin = cape_lcl = cin_lcl = cape_lfc = cin_lfc = cape_el = 0.0;
+        lfc_p = lfc_t = el_p = el_t = qnan(); lfc_idx = el_idx = -1;
+        any_inc = pos_parcel = env_any = false;
+        top_p = top_par = top_env = min_p = qnan();
+    }
+    XP_DEV void add(double a) {
+        if (isnan_(a)) return;                       // skip-NaN sums (pf.py:206)
+        if (!pos_neg || a > 0.0) cape += a;
+        if (!pos_neg || a < 0.0) cin += a;
+    }
+    XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
+        double y = par - env;
+        if (j == 0) {
+            use_all = (env != par);
+        } else {
+            int i = j - 1;
+            // sign(a-b).diff() != 0, NaN counts as flagged (pf.py:1019-1022)
+            bool ynan = isnan_(y) || isnan_(yp);
+            double s0 = (double)((yp > 0.0) - (yp < 0.0)), s1 = (double)((y > 0.0) - (y < 0.0));
+            bool flagged = ynan || (s1 != s0);
+            bool handled = false;
+            if (flagged) {
+                double xs = (y * Xp - yp * X) / (y - yp);                       // pf.py:1046
+                double frac = (xs - Xp) / (X - Xp);
+                double zy = frac * (y - yp) + yp;                               // zero crossing of y (pf.py:1225-1231)
+                if (!isnan_(zy)) {                                              // valid zero: two triangles (pf.py:1246-1273)
+                    handled = true;
+                    double ps = exp(xs);
+                    double zlog = log(ps);                                      // pf.py:1237
+                    add((yp * 0.5) * fabs(Xp - zlog));
+                    double ys = frac * (par - parp) + parp;                     // pf.py:1050
+                    if (!isnan_(ps)) {
+                        bool in_sel = use_all || i >= 1;
+                        if (y > 0.0 && in_sel) {                                // increasing crossing
+                            any_inc = true;
+                            if (ps < p_lcl && !(ps <= lfc_p)) {                 // bottom LFC above the LCL (pf.py:1127-1132)
+                                lfc_p = ps; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
+                            }
+                        }
+                        if (y < 0.0 && i >= 1 && !(ps >= el_p)) {               // top EL (pf.py:1136-1138)
+                            el_p = ps; el_t = ys; el_idx = i; cape_el = cape;
+                        }
+                    }
+                    add((y * 0.5) * fabs(X - zlog));
+                }
+            }
+            if (!handled) add(fabs(X - Xp) * ((yp + y) * 0.5));                 // pf.py:186-198
+        }
+        if (P < p_lcl && par > env) pos_parcel = true;                          // pf.py:1166-1169
+        if (!isnan_(env)) env_any = true;
+        if (!isnan_(P)) {
+            if (!(P >= min_p)) min_p = P;
+            if (!isnan_(par) && !isnan_(env)) {
+                if (!(P >= top_p)) { top_p = P; top_par = par; top_env = env; }
+                else if (P == top_p) { top_par = fmax(top_par, par); top_env = fmax(top_env, env); }
+            }
+        }
+        if (is_lcl) { cape_lcl = cape; cin_lcl = cin; }
+        Xp = X; yp = y; parp = par; ++j;
+    }
+    struct Result { double cape, cin, lfc_p, lfc_t, el_p, el_t; int lfc_idx, el_idx, status; };
+    XP_DEV Result finish(double lcl_t, bool post_zero) {
+        Result r;
+        r.status = 0;
+        // EL exists only if the parcel ends colder than the environment and the EL is above the LCL
+        bool el_ok = (top_par <= top_env) && (el_p < p_lcl);                    // pf.py:1151-1155
+        if (!el_ok) { el_p = qnan(); el_t = qnan(); el_idx = -1; }
+        if (isnan_(top_env) && env_any) r.status |= 1;                          // assert of pf.py:1149
+        bool lfc_missing = !any_inc;
+        bool replace = (pos_parcel && lfc_missing) ||
+                       (!lfc_missing && isnan_(lfc_p) && (el_p < p_lcl));       // pf.py:1161-1180
+        double L, cL, nL;
+        if (replace) { L = p_lcl; cL = cape_lcl; nL = cin_lcl; lfc_p = p_lcl; lfc_t = lcl_t; lfc_idx = -2; }
+        else { L = lfc_p; cL = cape_lfc; nL = cin_lfc; }
+        double E = el_ok ? el_p : min_p;                                        // pf.py:1329
+        double cE = el_ok ? cape_el : cape;
+        r.cape = (E < L) ? RD * (cE - cL) : 0.0;                                // NaN LFC -> comparisons false -> 0.0
+        r.cin = isnan_(L) ? 0.0 : RD * nL;
+        if (post_zero && !(r.cin <= 0.0)) r.cin = 0.0;                          // pf.py:1387-1388
+        r.lfc_p = lfc_p; r.lfc_t = lfc_t; r.el_p = el_p; r.el_t = el_t; r.lfc_idx = lfc_idx; r.el_idx = el_idx;
+        return r;
+    }
+};
+
+}  // namespace xp

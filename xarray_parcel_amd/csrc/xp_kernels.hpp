@@ -1,0 +1,415 @@
+// xp_kernels.hpp -- HIP kernels of libxparcel: one thread = one column, lanes of a wavefront own
+// x-adjacent columns so every level read is one coalesced 256 B (fp32) / 512 B (fp64) request per
+// array (layout (lev, y, x), col_stride == 1).  No LDS, no MFMA: the path is an elementwise +
+// per-column scan.
+#pragma once
+#include "xp_device.hpp"
+
+namespace xp {
+
+struct View { const void *data; int64_t ls, cs; };           // element strides
+struct OutView { void *data; int64_t ls, cs; };
+
+template <typename T> XP_DEV double ld(const View &v, int64_t k, int64_t c) {
+    return (double)((const T *)v.data)[k * v.ls + c * v.cs];
+}
+template <typename T> XP_DEV double ld1(const void *p, int64_t c) { return (double)((const T *)p)[c]; }
+XP_DEV void st(void *p, int f64, int64_t i, double v) {
+    if (p == nullptr) return;
+    if (f64) ((double *)p)[i] = v; else ((float *)p)[i] = (float)v;
+}
+XP_DEV void sti(int32_t *p, int64_t i, int v) { if (p) p[i] = v; }
+
+struct ScalarsOut {
+    void *cape, *cin, *lcl_p, *lcl_t, *lcl_tv, *lfc_p, *lfc_t, *el_p, *el_t;
+    int32_t *lfc_idx, *el_idx, *status, *parcel_idx;
+    void *par_p, *par_t, *par_td;
+    int f64;
+};
+struct ProfileOut {
+    void *v[6];            // p, t_parcel, tv_parcel, t_env, tv_env, td_env
+    int64_t nlev_out, ls, cs;
+    int f64;
+};
+struct CapeArgs {
+    View p, t, td;
+    int64_t nlev, ncol;
+    const void *ex_p, *ex_t, *ex_td;      // explicit parcel
+    double depth;
+    int vtc, log_interp, pos_neg, post_zero, table_mode;
+    Tables tb;
+    ScalarsOut s;
+    ProfileOut prof;
+};
+
+enum { PM_SURFACE = 0, PM_MU = 1, PM_ML = 2, PM_EXPLICIT = 3 };
+
+struct Parcel { double p, t, td; int64_t first; int idx; bool prepend; };
+
+// most_unstable_parcel (pf.py:102-135 with get_layer pf.py:63-100 and bound_pressure pf.py:208-227):
+// highest theta-e in the lowest `depth` hPa, first maximum wins; the layer top is the level closest to
+// p_bottom - depth (ties -> higher pressure).
+template <typename T> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c) {
+    Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
+    double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
+    for (int64_t k = 0; k < a.nlev; ++k) {
+        double p = ld<T>(a.p, k, c);
+        if (isnan_(p)) continue;
+        if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
+        double d = fabs(p - bound);
+        bool below = p < bound;
+        if (below && !(d < dmin)) break;                  // the level above the bound is at least as close
+        if (!(d >= dmin)) dmin = d;
+        double t = ld<T>(a.t, k, c), td = ld<T>(a.td, k, c);
+        double e = theta_e(p, t, td);
+        if (!isnan_(e) && !(e <= best)) { best = e; r.p = p; r.t = t; r.td = td; r.first = k; r.idx = (int)k; }
+        if (below) break;
+    }
+    return r;
+}
+
+// mixed_parcel (pf.py:229-289) with mixed_layer (pf.py:137-162) / get_layer(interpolate=True):
+// trapezoid in linear p of theta and w_s(p, Td) over [p_bottom - depth, p_bottom], top interpolated in ln p.
+template <typename T> XP_DEV void layer_mean_step(double &sum, double p0, double v0, double p1, double v1) {
+    double a = fabs(p1 - p0) * ((v0 + v1) * 0.5);
+    if (!isnan_(a)) sum += a;
+}
+XP_DEV double interp_rule(double xb, double xa, double at, double cb, double ca) {   // pf.py:1798-1806
+    double res = xb + (xa - xb) * ((at - cb) / (ca - cb));
+    return (xb == xa) ? xb : res;
+}
+template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
+    Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = true;
+    double p_start = ld<T>(a.p, 0, c);
+    double bottom = qnan(), top = qnan();
+    double s_th = 0.0, s_w = 0.0;
+    double pp = qnan(), thp = qnan(), wp = qnan();        // previous row of the layer
+    double pb = qnan(), thb = qnan(), wb = qnan();        // last row with a valid pressure >= top
+    bool closed = false;
+    for (int64_t k = 0; k < a.nlev; ++k) {
+        double p = ld<T>(a.p, k, c), t = ld<T>(a.t, k, c), td = ld<T>(a.td, k, c);
+        if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - a.depth; }
+        if (!isnan_(p) && p < top) {
+            // insert the interpolated top row, close the integral; the profile continues from this level
+            double lt = log(top), cb = log(pb), ca = log(p);
+            double th_a = t / pow(p / 1000.0, KAPPA), w_a = sat_mix(p, td);
+            double cb2 = cb, ca2 = ca, tha = th_a, wa = w_a;
+            if (pb == top) { ca2 = cb; tha = thb; wa = wb; }
+            double th_t = interp_rule(thb, tha, lt, cb2, ca2), w_t = interp_rule(wb, wa, lt, cb2, ca2);
+            layer_mean_step<T>(s_th, pp, thp, top, th_t);
+            layer_mean_step<T>(s_w, pp, wp, top, w_t);
+            r.first = k; closed = true;
+            break;
+        }
+        double th = t / pow(p / 1000.0, KAPPA), w = sat_mix(p, td);
+        if (k > 0) { layer_mean_step<T>(s_th, pp, thp, p, th); layer_mean_step<T>(s_w, pp, wp, p, w); }
+        pp = p; thp = th; wp = w;
+        if (!isnan_(p)) { pb = p; thb = th; wb = w; }
+    }
+    if (!closed) {
+        // column never gets above the layer top: the inserted row holds NaN unless a level sits exactly on it
+        double th_t = (pb == top) ? thb : qnan(), w_t = (pb == top) ? wb : qnan();
+        layer_mean_step<T>(s_th, pp, thp, top, th_t);
+        layer_mean_step<T>(s_w, pp, wp, top, w_t);
+    }
+    double depth = fabs(top - bottom);
+    double th_m = (1.0 / depth) * s_th, w_m = (1.0 / depth) * s_w;
+    r.p = p_start;                                                         // pf.py:250, 287
+    r.t = th_m * pow(p_start / 1000.0, KAPPA);                             // pf.py:268-269
+    r.td = dewpoint_of_e(vapor_pressure(p_start, w_m));                    // pf.py:275-280
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cape_cin (pf.py:1394-1475) and its drivers, fused: parcel selection, LCL, parcel profile with
+// the LCL as a virtual level, LFC/EL, CAPE/CIN, optional profile output.
+template <typename T, int PMODE, bool PROFILE>
+__global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ncol) return;
+
+    Parcel pc;
+    if (PMODE == PM_SURFACE) {
+        pc.p = ld<T>(a.p, 0, c); pc.t = ld<T>(a.t, 0, c); pc.td = ld<T>(a.td, 0, c);
+        pc.first = 0; pc.idx = 0; pc.prepend = false;
+    } else if (PMODE == PM_EXPLICIT) {
+        pc.p = ld1<T>(a.ex_p, c); pc.t = ld1<T>(a.ex_t, c); pc.td = ld1<T>(a.ex_td, c);
+        pc.first = 0; pc.idx = -1; pc.prepend = false;
+    } else if (PMODE == PM_MU) {
+        pc = select_mu<T>(a, c);
+    } else {
+        pc = select_ml<T>(a, c);
+    }
+
+    const bool need_w = a.vtc || PROFILE;
+    Lcl l = lcl(pc.p, pc.t, pc.td);
+    int status = l.not_converged ? 2 : 0;
+    const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
+    double w_parcel = need_w ? mixing_ratio(pc.t, pc.td, pc.p) : 0.0;      // pf.py:748
+    const double x0 = log(pc.p), x_lcl = log(l.p);
+
+    Scan sc; sc.init(l.p, a.pos_neg != 0);
+    Moist m; m.start(l.p, x_lcl, l.t, a.table_mode != 0, a.tb);
+
+    int64_t jout = 0;                                                      // profile row
+    auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) {
+        if (PROFILE) {
+            if (jout < a.prof.nlev_out) {
+                int64_t o = jout * a.prof.ls + c * a.prof.cs;
+                bool dead = isnan_(P);                                     // NaN-coordinate rows come out all-NaN (pf.py:963, 988)
+                st(a.prof.v[0], a.prof.f64, o, P);
+                st(a.prof.v[1], a.prof.f64, o, dead ? P : tp);
+                st(a.prof.v[2], a.prof.f64, o, dead ? P : tvp);
+                st(a.prof.v[3], a.prof.f64, o, dead ? P : te);
+                st(a.prof.v[4], a.prof.f64, o, dead ? P : tve);
+                st(a.prof.v[5], a.prof.f64, o, dead ? P : tde);
+            }
+            ++jout;
+        }
+        sc.node(P, X, a.vtc ? tvp : tp, a.vtc ? tve : te, is_lcl);
+    };
+
+    const bool lcl_nan = isnan_(l.p);
+    bool lcl_done = false;
+    double pb = qnan(), xb = qnan(), tb_ = qnan(), tdb = qnan();          // last valid-pressure node at or below the LCL
+    auto emit_lcl = [&](double pa, double xa, double ta, double tda) {
+        // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811),
+        // then virtual temperature recomputed from the interpolated T, Td (pf.py:911-920)
+        double at = a.log_interp ? x_lcl : l.p;
+        double cb = a.log_interp ? xb : pb, ca = a.log_interp ? xa : pa;
+        double ta2 = ta, tda2 = tda;
+        if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
+        double te = interp_rule(tb_, ta2, at, cb, ca), tde = interp_rule(tdb, tda2, at, cb, ca);
+        double tve = need_w ? virt(te, mixing_ratio(te, tde, l.p)) : te;
+        emit(l.p, x_lcl, l.t, l.tv, te, tve, tde, true);
+        lcl_done = true;
+    };
+    auto source = [&](double P, double T_, double Td_) {
+        double X = log(P);
+        if (!lcl_done && !lcl_nan && P < l.p) emit_lcl(P, X, T_, Td_);
+        double tp, w;
+        if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
+            tp = pc.t * exp(KAPPA * (X - x0));
+            w = w_parcel;
+            if (need_w && P == l.p) w = mix_of_e(sat_vapor_pressure(m.at(P, X, a.tb)), P);   // pf.py:773 (<=)
+        } else {
+            tp = m.at(P, X, a.tb);                                         // NaN pressure -> NaN
+            w = need_w ? mix_of_e(sat_vapor_pressure(tp), P) : 0.0;        // pf.py:760
+        }
+        double tvp = need_w ? virt(tp, w) : tp;
+        double tve = need_w ? virt(T_, mixing_ratio(T_, Td_, P)) : T_;     // pf.py:839-843
+        if (lcl_nan) { P = X = tp = tvp = T_ = tve = Td_ = qnan(); }       // NaN LCL blanks the whole profile (pf.py:965-985)
+        emit(P, X, tp, tvp, T_, tve, Td_, false);
+        if (!isnan_(P) && !lcl_done) { pb = P; xb = X; tb_ = T_; tdb = Td_; }
+        else if (isnan_(P) && !lcl_done) status |= 4;
+    };
+
+    if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
+    // software-prefetched level loop
+    int64_t k = pc.first;
+    double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
+    if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
+    for (; k < a.nlev; ++k) {
+        double P = np_, T_ = nt_, Td_ = ntd_;
+        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        source(P, T_, Td_);
+    }
+    if (!lcl_done) {
+        if (lcl_nan) emit(qnan(), qnan(), qnan(), qnan(), qnan(), qnan(), qnan(), true);
+        else emit_lcl(qnan(), qnan(), qnan(), qnan());                     // LCL above the top level: no upper bracket
+    }
+    if (PROFILE) {
+        for (; jout < a.prof.nlev_out; ++jout) {
+            int64_t o = jout * a.prof.ls + c * a.prof.cs;
+            for (int v = 0; v < 6; ++v) st(a.prof.v[v], a.prof.f64, o, qnan());
+        }
+    }
+
+    Scan::Result r = sc.finish(lcl_t_arg, a.post_zero != 0);
+    status |= r.status;
+    const ScalarsOut &s = a.s;
+    st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
+    st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
+    st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t);
+    st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
+    sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, status); sti(s.parcel_idx, c, pc.idx);
+    st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
+}
+
+// parcels only (most_unstable_parcel pf.py:102, mixed_parcel pf.py:229)
+template <typename T, int PMODE> __global__ __launch_bounds__(256) void k_select_parcel(CapeArgs a) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ncol) return;
+    Parcel pc = (PMODE == PM_MU) ? select_mu<T>(a, c) : select_ml<T>(a, c);
+    st(a.s.par_p, a.s.f64, c, pc.p); st(a.s.par_t, a.s.f64, c, pc.t); st(a.s.par_td, a.s.f64, c, pc.td);
+    sti(a.s.parcel_idx, c, pc.idx);
+}
+
+// mixed_layer (pf.py:137-162) of one variable
+template <typename T> __global__ __launch_bounds__(256)
+void k_mixed_layer(View pv, View vv, int64_t nlev, int64_t ncol, double depth_in, void *out, int f64) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double bottom = qnan(), top = qnan(), s = 0.0, pp = qnan(), vp = qnan(), pb = qnan(), vb = qnan();
+    bool closed = false;
+    for (int64_t k = 0; k < nlev; ++k) {
+        double p = ld<T>(pv, k, c), v = ld<T>(vv, k, c);
+        if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - depth_in; }
+        if (!isnan_(p) && p < top) {
+            double cb = log(pb), ca = log(p), va = v;
+            if (pb == top) { ca = cb; va = vb; }
+            layer_mean_step<T>(s, pp, vp, top, interp_rule(vb, va, log(top), cb, ca));
+            closed = true;
+            break;
+        }
+        if (k > 0) layer_mean_step<T>(s, pp, vp, p, v);
+        pp = p; vp = v;
+        if (!isnan_(p)) { pb = p; vb = v; }
+    }
+    if (!closed) layer_mean_step<T>(s, pp, vp, top, (pb == top) ? vb : qnan());
+    st(out, f64, c, (1.0 / fabs(top - bottom)) * s);
+}
+
+// lcl (pf.py:609-682) on n parcels
+template <typename T> __global__ __launch_bounds__(256)
+void k_lcl(int64_t n, const void *p, const void *t, const void *td, void *op, void *ot, void *otv, int32_t *status) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    Lcl l = lcl(ld1<T>(p, c), ld1<T>(t, c), ld1<T>(td, c));
+    const int f64 = sizeof(T) == 8;
+    st(op, f64, c, l.p); st(ot, f64, c, l.t); st(otv, f64, c, l.tv); sti(status, c, l.not_converged ? 2 : 0);
+}
+
+// dry_lapse (pf.py:291-316); parcel pressure defaults to the column maximum
+template <typename T> __global__ __launch_bounds__(256)
+void k_dry_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void *pp, OutView out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double t0 = ld1<T>(pt, c), p0 = qnan();
+    if (pp) p0 = ld1<T>(pp, c);
+    else for (int64_t k = 0; k < nlev; ++k) { double p = ld<T>(pv, k, c); if (!isnan_(p) && !(p <= p0)) p0 = p; }
+    for (int64_t k = 0; k < nlev; ++k) {
+        double p = ld<T>(pv, k, c);
+        st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, t0 * pow(p / p0, KAPPA));
+    }
+}
+
+// moist_lapse (pf.py:525-607): levels in any order relative to the parcel pressure.  Levels at or above the
+// reference (p <= p_ref) are marched upwards in level order, levels below it downwards in reverse level order
+// (pressure must decrease with level index on each side, the reference's input contract).
+template <typename T> __global__ __launch_bounds__(256)
+void k_moist_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void *pp, int table_mode, Tables tb,
+                   OutView out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const int f64 = sizeof(T) == 8;
+    double t0 = ld1<T>(pt, c);
+    double p0 = pp ? ld1<T>(pp, c) : ld<T>(pv, 0, c);                      // pf.py:549-550
+    double x0 = log(p0);
+    Moist m; m.start(p0, x0, t0, table_mode != 0, tb);
+    for (int64_t k = 0; k < nlev; ++k) {
+        double p = ld<T>(pv, k, c);
+        if (p <= p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, log(p), tb));
+        else if (isnan_(p)) st(out.data, f64, k * out.ls + c * out.cs, qnan());
+    }
+    m.start(p0, x0, t0, table_mode != 0, tb);
+    for (int64_t k = nlev - 1; k >= 0; --k) {
+        double p = ld<T>(pv, k, c);
+        if (p > p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, log(p), tb));
+    }
+}
+
+// parcel_profile (pf.py:712-780) without the LCL level
+template <typename T> __global__ __launch_bounds__(256)
+void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const void *pt, const void *ptd,
+                      int table_mode, Tables tb, OutView ot, OutView otv, void *olp, void *olt, void *oltv) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const int f64 = sizeof(T) == 8;
+    double p0 = ld1<T>(pp, c), t0 = ld1<T>(pt, c), td0 = ld1<T>(ptd, c);
+    Lcl l = lcl(p0, t0, td0);
+    double w_parcel = mixing_ratio(t0, td0, p0);
+    double x_lcl = log(l.p);
+    Moist m; m.start(l.p, x_lcl, l.t, table_mode != 0, tb);
+    for (int64_t k = 0; k < nlev; ++k) {
+        double P = ld<T>(pv, k, c);
+        double tp, w;
+        if (P >= l.p) {
+            tp = t0 * pow(P / p0, KAPPA);
+            w = (P == l.p) ? mix_of_e(sat_vapor_pressure(l.t), P) : w_parcel;
+        } else {
+            tp = m.at(P, log(P), tb);
+            w = mix_of_e(sat_vapor_pressure(tp), P);
+        }
+        if (ot.data) st(ot.data, f64, k * ot.ls + c * ot.cs, tp);
+        if (otv.data) st(otv.data, f64, k * otv.ls + c * otv.cs, virt(tp, w));
+    }
+    st(olp, f64, c, l.p); st(olt, f64, c, l.t); st(oltv, f64, c, l.tv);
+}
+
+// lfc_el (pf.py:1066-1198) on caller-supplied profiles: the same state machine, fed directly
+template <typename T> __global__ __launch_bounds__(256)
+void k_lfc_el(View pv, View parv, View envv, int64_t nlev, int64_t ncol, const void *lcl_p, const void *lcl_t,
+              ScalarsOut s) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double lp = ld1<T>(lcl_p, c), lt = ld1<T>(lcl_t, c);
+    Scan sc; sc.init(lp, true);
+    for (int64_t k = 0; k < nlev; ++k) {
+        double P = ld<T>(pv, k, c);
+        sc.node(P, log(P), ld<T>(parv, k, c), ld<T>(envv, k, c), false);
+    }
+    Scan::Result r = sc.finish(lt, false);
+    st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t); st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
+    sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, r.status);
+}
+
+// cape_cin_base (pf.py:1291-1392) on caller-supplied profiles and LFC/EL: direct form (LFC and EL are
+// known up front, so every area is tested against them as the reference does, no snapshots).
+template <typename T> __global__ __launch_bounds__(256)
+void k_cape_cin_base(View pv, View envv, View parv, int64_t nlev, int64_t ncol, const void *lfc_p, const void *el_p,
+                     int pos_neg, int post_zero, void *cape, void *cin) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const int f64 = sizeof(T) == 8;
+    double L = ld1<T>(lfc_p, c), E = ld1<T>(el_p, c);
+    if (isnan_(E)) {                                                       // pf.py:1329
+        for (int64_t k = 0; k < nlev; ++k) { double p = ld<T>(pv, k, c); if (!isnan_(p) && !(p >= E)) E = p; }
+    }
+    double sc_ = 0.0, sn = 0.0, Pp = qnan(), Xp = qnan(), yp = qnan();
+    for (int64_t k = 0; k < nlev; ++k) {
+        double P = ld<T>(pv, k, c), X = log(P), y = ld<T>(parv, k, c) - ld<T>(envv, k, c);
+        if (k > 0) {
+            bool ynan = isnan_(y) || isnan_(yp);
+            double s0 = (double)((yp > 0.0) - (yp < 0.0)), s1 = (double)((y > 0.0) - (y < 0.0));
+            bool handled = false;
+            if (ynan || s1 != s0) {
+                double xs = (y * Xp - yp * X) / (y - yp);
+                double zy = ((xs - Xp) / (X - Xp)) * (y - yp) + yp;
+                if (!isnan_(zy)) {
+                    handled = true;
+                    double zlog = log(exp(xs));
+                    double dx = Xp - zlog, a0 = (yp * 0.5) * fabs(dx), pm = exp(Xp - dx * 0.5);
+                    if (pm <= L && pm >= E && (!pos_neg || a0 > 0.0)) sc_ += a0;
+                    if (pm >= L && (!pos_neg || a0 < 0.0)) sn += a0;
+                    dx = X - zlog; a0 = (y * 0.5) * fabs(dx); pm = exp(X - dx * 0.5);
+                    if (pm <= L && pm >= E && (!pos_neg || a0 > 0.0)) sc_ += a0;
+                    if (pm >= L && (!pos_neg || a0 < 0.0)) sn += a0;
+                }
+            }
+            if (!handled) {
+                double a0 = fabs(X - Xp) * ((yp + y) * 0.5);
+                if (!isnan_(a0)) {
+                    if (Pp <= L && Pp >= E && P <= L && P >= E && (!pos_neg || a0 > 0.0)) sc_ += a0;
+                    if (Pp >= L && P >= L && (!pos_neg || a0 < 0.0)) sn += a0;
+                }
+            }
+        }
+        Pp = P; Xp = X; yp = y;
+    }
+    double cin_v = RD * sn;
+    if (post_zero && !(cin_v <= 0.0)) cin_v = 0.0;
+    st(cape, f64, c, RD * sc_); st(cin, f64, c, cin_v);
+}
+
+}  // namespace xp

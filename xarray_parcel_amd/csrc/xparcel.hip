@@ -1,0 +1,418 @@
+// xparcel.hip -- C ABI of libxparcel (include/xparcel.h): argument checking, host<->device staging,
+// kernel dispatch.  Everything numerical lives in xp_device.hpp / xp_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/xparcel.h"
+#include "xp_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(XP_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+struct State {
+    std::mutex mu;
+    bool init = false;
+    int device = -1;
+    bool tables = false;
+    xp::Tables tb{};
+    void *tb_index = nullptr, *tb_adiabats = nullptr;
+} g;
+
+size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
+
+// Stages host buffers through device scratch for one call; device buffers pass through.
+struct Stager {
+    hipStream_t s;
+    struct Back { void *host; void *dev; size_t bytes; };
+    std::vector<void *> scratch;
+    std::vector<Back> back;
+    bool any_host = false;
+    explicit Stager(void *stream) : s((hipStream_t)stream) {}
+    ~Stager() { for (void *p : scratch) (void)hipFree(p); }
+    int in(const void *p, size_t bytes, int mem, const void **out) {
+        *out = p;
+        if (p == nullptr || mem == XP_MEM_DEVICE) return 0;
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes ? bytes : 1));
+        scratch.push_back(d);
+        HIP_TRY(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s));
+        any_host = true;
+        *out = d;
+        return 0;
+    }
+    int out(void *p, size_t bytes, int mem, void **dev) {
+        *dev = p;
+        if (p == nullptr || mem == XP_MEM_DEVICE) return 0;
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes ? bytes : 1));
+        scratch.push_back(d);
+        back.push_back({p, d, bytes});
+        any_host = true;
+        *dev = d;
+        return 0;
+    }
+    int finish() {
+        HIP_TRY(hipGetLastError());
+        for (const Back &b : back) HIP_TRY(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s));
+        if (any_host) HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
+};
+
+int check_view(const xp_view *v, const char *name) {
+    if (!v || !v->data) return fail(XP_E_ARG, "%s: null view", name);
+    if (v->dtype != XP_F32 && v->dtype != XP_F64) return fail(XP_E_ARG, "%s: dtype must be XP_F32 or XP_F64", name);
+    if (v->nlev < 1 || v->ncol < 0) return fail(XP_E_ARG, "%s: bad shape (%lld, %lld)", name, (long long)v->nlev, (long long)v->ncol);
+    if (v->mem == XP_MEM_HOST && !(v->col_stride == 1 && v->lev_stride == v->ncol))
+        return fail(XP_E_ARG, "%s: host views must be dense (nlev, ncol) C-order", name);
+    return 0;
+}
+int same_shape(const xp_view *a, const xp_view *b, const char *what) {
+    if (a->nlev != b->nlev || a->ncol != b->ncol || a->dtype != b->dtype)
+        return fail(XP_E_ARG, "%s: views differ in shape or dtype", what);
+    return 0;
+}
+int stage_view(Stager &st, const xp_view *v, xp::View *out) {
+    const void *d;
+    int rc = st.in(v->data, (size_t)v->nlev * (size_t)v->ncol * esize(v->dtype), v->mem, &d);
+    if (rc) return rc;
+    out->data = d; out->ls = v->lev_stride; out->cs = v->col_stride;
+    return 0;
+}
+int ensure_init() {
+    if (!g.init) return fail(XP_E_NOT_INIT, "xp_init() has not been called");
+    hipError_t e = hipSetDevice(g.device);
+    if (e != hipSuccess) return fail(XP_E_HIP, "hipSetDevice(%d): %s", g.device, hipGetErrorString(e));
+    return 0;
+}
+unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+int stage_scalars(Stager &st, xp_scalars_out *s, int64_t ncol, xp::ScalarsOut *o) {
+    memset(o, 0, sizeof(*o));
+    if (!s) { o->f64 = 1; return 0; }
+    if (s->dtype != XP_F32 && s->dtype != XP_F64) return fail(XP_E_ARG, "scalars: bad dtype");
+    o->f64 = s->dtype == XP_F64;
+    size_t fb = (size_t)ncol * esize(s->dtype), ib = (size_t)ncol * 4;
+    int rc = 0;
+#define F_(dst, src) if (!rc) rc = st.out(s->src, fb, s->mem, &o->dst)
+#define I_(dst, src) if (!rc) { void *t_; rc = st.out(s->src, ib, s->mem, &t_); o->dst = (int32_t *)t_; }
+    F_(cape, cape); F_(cin, cin); F_(lcl_p, lcl_pressure); F_(lcl_t, lcl_temperature); F_(lcl_tv, lcl_virtual_temperature);
+    F_(lfc_p, lfc_pressure); F_(lfc_t, lfc_temperature); F_(el_p, el_pressure); F_(el_t, el_temperature);
+    I_(lfc_idx, lfc_index); I_(el_idx, el_index); I_(status, status); I_(parcel_idx, parcel_index);
+    F_(par_p, parcel_pressure); F_(par_t, parcel_temperature); F_(par_td, parcel_dewpoint);
+#undef F_
+#undef I_
+    return rc;
+}
+
+template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
+    if (a.ncol == 0) return;
+    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+}
+template <typename T> void launch_cape_pm(const xp::CapeArgs &a, int pm, bool profile, hipStream_t s) {
+    switch (pm) {
+        case XP_PARCEL_SURFACE: launch_cape<T, xp::PM_SURFACE>(a, profile, s); break;
+        case XP_PARCEL_MOST_UNSTABLE: launch_cape<T, xp::PM_MU>(a, profile, s); break;
+        case XP_PARCEL_MIXED_LAYER: launch_cape<T, xp::PM_ML>(a, profile, s); break;
+        default: launch_cape<T, xp::PM_EXPLICIT>(a, profile, s); break;
+    }
+}
+
+int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel,
+                const xp_opts *o, xp::CapeArgs *a) {
+    int rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(td, "dewpoint"))) return rc;
+    if ((rc = same_shape(p, t, "pressure/temperature")) || (rc = same_shape(p, td, "pressure/dewpoint"))) return rc;
+    if (!parcel) return fail(XP_E_ARG, "parcel: null");
+    if (parcel->mode < XP_PARCEL_SURFACE || parcel->mode > XP_PARCEL_EXPLICIT) return fail(XP_E_ARG, "parcel: bad mode");
+    memset(a, 0, sizeof(*a));
+    if ((rc = stage_view(st, p, &a->p)) || (rc = stage_view(st, t, &a->t)) || (rc = stage_view(st, td, &a->td))) return rc;
+    a->nlev = p->nlev; a->ncol = p->ncol;
+    a->depth = parcel->depth;
+    if (parcel->mode == XP_PARCEL_EXPLICIT) {
+        if (!parcel->pressure || !parcel->temperature || !parcel->dewpoint) return fail(XP_E_ARG, "explicit parcel: null arrays");
+        size_t b = (size_t)p->ncol * esize(p->dtype);
+        if ((rc = st.in(parcel->pressure, b, p->mem, &a->ex_p)) || (rc = st.in(parcel->temperature, b, p->mem, &a->ex_t)) ||
+            (rc = st.in(parcel->dewpoint, b, p->mem, &a->ex_td))) return rc;
+    }
+    if (o) {
+        if (o->lcl_interp != XP_LCL_INTERP_LINEAR && o->lcl_interp != XP_LCL_INTERP_LOG)
+            return fail(XP_E_INTERP, "interpolator must be linear or log");
+        if (o->moist_mode != XP_MOIST_EXACT && o->moist_mode != XP_MOIST_TABLE) return fail(XP_E_ARG, "bad moist_mode");
+        a->vtc = o->virtual_temperature_correction; a->log_interp = o->lcl_interp == XP_LCL_INTERP_LOG;
+        a->pos_neg = o->pos_cape_neg_cin; a->post_zero = o->post_zero_cin; a->table_mode = o->moist_mode == XP_MOIST_TABLE;
+    } else {
+        a->vtc = 1; a->log_interp = 1; a->pos_neg = 1; a->post_zero = 0; a->table_mode = 0;
+    }
+    if (a->table_mode) {
+        if (!g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
+        a->tb = g.tb;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xp_version(void) { return XP_VERSION; }
+const char *xp_last_error(void) { return g_err; }
+
+int xp_init(int device) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(XP_E_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(XP_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    if (g.init && g.device != device && g.tables) {
+        // tables live on the old device; drop them, the caller reloads
+        (void)hipFree(g.tb_index); (void)hipFree(g.tb_adiabats);
+        g.tb_index = g.tb_adiabats = nullptr; g.tables = false;
+    }
+    g.device = device;
+    g.init = true;
+    return XP_OK;
+}
+
+int xp_set_tables(const xp_tables *t) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!t || !t->index || !t->adiabats || t->n_pressure < 2 || t->n_temperature < 2 || t->n_adiabat < 1)
+        return fail(XP_E_ARG, "xp_set_tables: bad tables");
+    if (g.tables) { (void)hipFree(g.tb_index); (void)hipFree(g.tb_adiabats); g.tables = false; }
+    size_t ib = (size_t)t->n_pressure * (size_t)t->n_temperature * 2, ab = (size_t)t->n_adiabat * (size_t)t->n_pressure * 4;
+    HIP_TRY(hipMalloc(&g.tb_index, ib));
+    HIP_TRY(hipMalloc(&g.tb_adiabats, ab));
+    HIP_TRY(hipMemcpy(g.tb_index, t->index, ib, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.tb_adiabats, t->adiabats, ab, hipMemcpyHostToDevice));
+    g.tb.index = (const uint16_t *)g.tb_index; g.tb.adiabats = (const float *)g.tb_adiabats;
+    g.tb.n_p = t->n_pressure; g.tb.n_t = t->n_temperature;
+    g.tb.p_max = t->p_max; g.tb.p_step = t->p_step; g.tb.t_min = t->t_min; g.tb.t_step = t->t_step;
+    g.tables = true;
+    return XP_OK;
+}
+int xp_tables_loaded(void) { return g.tables ? 1 : 0; }
+
+int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel, const xp_opts *o,
+                xp_scalars_out *scalars, xp_profile_out *profile, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    Stager st(stream);
+    xp::CapeArgs a;
+    if ((rc = fill_common(st, p, t, td, parcel, o, &a))) return rc;
+    if ((rc = stage_scalars(st, scalars, a.ncol, &a.s))) return rc;
+    if (profile) {
+        if (profile->dtype != XP_F32 && profile->dtype != XP_F64) return fail(XP_E_ARG, "profile: bad dtype");
+        if (profile->nlev_out < a.nlev + 1) return fail(XP_E_ARG, "profile: nlev_out must be >= nlev + 1");
+        if (profile->mem == XP_MEM_HOST && !(profile->col_stride == 1 && profile->lev_stride == a.ncol))
+            return fail(XP_E_ARG, "profile: host arrays must be dense (nlev_out, ncol)");
+        void *src[6] = {profile->pressure, profile->temperature, profile->virtual_temperature,
+                        profile->environment_temperature, profile->environment_virtual_temperature,
+                        profile->environment_dewpoint};
+        size_t b = (size_t)profile->nlev_out * (size_t)a.ncol * esize(profile->dtype);
+        for (int v = 0; v < 6; ++v)
+            if ((rc = st.out(src[v], b, profile->mem, &a.prof.v[v]))) return rc;
+        a.prof.nlev_out = profile->nlev_out; a.prof.ls = profile->lev_stride; a.prof.cs = profile->col_stride;
+        a.prof.f64 = profile->dtype == XP_F64;
+    }
+    if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
+    else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
+    return st.finish();
+}
+
+int xp_select_parcel(const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel,
+                     xp_scalars_out *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    Stager st(stream);
+    xp::CapeArgs a;
+    if ((rc = fill_common(st, p, t, td, parcel, nullptr, &a))) return rc;
+    if (parcel->mode != XP_PARCEL_MOST_UNSTABLE && parcel->mode != XP_PARCEL_MIXED_LAYER)
+        return fail(XP_E_ARG, "xp_select_parcel: mode must be most-unstable or mixed-layer");
+    if ((rc = stage_scalars(st, out, a.ncol, &a.s))) return rc;
+    if (a.ncol) {
+        dim3 gr(blocks(a.ncol)), bl(256);
+        if (p->dtype == XP_F64) {
+            if (parcel->mode == XP_PARCEL_MOST_UNSTABLE) hipLaunchKernelGGL((xp::k_select_parcel<double, xp::PM_MU>), gr, bl, 0, st.s, a);
+            else hipLaunchKernelGGL((xp::k_select_parcel<double, xp::PM_ML>), gr, bl, 0, st.s, a);
+        } else {
+            if (parcel->mode == XP_PARCEL_MOST_UNSTABLE) hipLaunchKernelGGL((xp::k_select_parcel<float, xp::PM_MU>), gr, bl, 0, st.s, a);
+            else hipLaunchKernelGGL((xp::k_select_parcel<float, xp::PM_ML>), gr, bl, 0, st.s, a);
+        }
+    }
+    return st.finish();
+}
+
+int xp_mixed_layer(const xp_view *p, const xp_view *v, double depth, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(v, "variable")) || (rc = same_shape(p, v, "pressure/variable"))) return rc;
+    if (!out) return fail(XP_E_ARG, "xp_mixed_layer: null output");
+    Stager st(stream);
+    xp::View pv, vv;
+    void *od;
+    if ((rc = stage_view(st, p, &pv)) || (rc = stage_view(st, v, &vv)) ||
+        (rc = st.out(out, (size_t)p->ncol * esize(p->dtype), p->mem, &od))) return rc;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_mixed_layer<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, vv, p->nlev, p->ncol, depth, od, 1);
+        else hipLaunchKernelGGL((xp::k_mixed_layer<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, vv, p->nlev, p->ncol, depth, od, 0);
+    }
+    return st.finish();
+}
+
+int xp_lcl(int64_t n, int32_t dtype, int32_t mem, const void *pp, const void *pt, const void *ptd, void *lp, void *lt,
+           void *ltv, int32_t *status, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n < 0 || !pp || !pt || !ptd) return fail(XP_E_ARG, "xp_lcl: null input");
+    if (dtype != XP_F32 && dtype != XP_F64) return fail(XP_E_ARG, "xp_lcl: bad dtype");
+    Stager st(stream);
+    size_t b = (size_t)n * esize(dtype);
+    const void *dp, *dt, *dtd;
+    void *op, *ot, *otv, *os;
+    if ((rc = st.in(pp, b, mem, &dp)) || (rc = st.in(pt, b, mem, &dt)) || (rc = st.in(ptd, b, mem, &dtd)) ||
+        (rc = st.out(lp, b, mem, &op)) || (rc = st.out(lt, b, mem, &ot)) || (rc = st.out(ltv, b, mem, &otv)) ||
+        (rc = st.out(status, (size_t)n * 4, mem, &os))) return rc;
+    if (n) {
+        if (dtype == XP_F64) hipLaunchKernelGGL((xp::k_lcl<double>), dim3(blocks(n)), dim3(256), 0, st.s, n, dp, dt, dtd, op, ot, otv, (int32_t *)os);
+        else hipLaunchKernelGGL((xp::k_lcl<float>), dim3(blocks(n)), dim3(256), 0, st.s, n, dp, dt, dtd, op, ot, otv, (int32_t *)os);
+    }
+    return st.finish();
+}
+
+int xp_dry_lapse(const xp_view *p, const void *pt, const void *pp, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure"))) return rc;
+    if (!pt || !out) return fail(XP_E_ARG, "xp_dry_lapse: null argument");
+    Stager st(stream);
+    xp::View pv; xp::OutView ov;
+    size_t cb = (size_t)p->ncol * esize(p->dtype), fb = cb * (size_t)p->nlev;
+    const void *dt, *dp;
+    void *od;
+    if ((rc = stage_view(st, p, &pv)) || (rc = st.in(pt, cb, p->mem, &dt)) || (rc = st.in(pp, cb, p->mem, &dp)) ||
+        (rc = st.out(out, fb, p->mem, &od))) return rc;
+    ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_dry_lapse<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, ov);
+        else hipLaunchKernelGGL((xp::k_dry_lapse<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, ov);
+    }
+    return st.finish();
+}
+
+int xp_moist_lapse(const xp_view *p, const void *pt, const void *pp, int32_t moist_mode, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure"))) return rc;
+    if (!pt || !out) return fail(XP_E_ARG, "xp_moist_lapse: null argument");
+    if (moist_mode == XP_MOIST_TABLE && !g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
+    Stager st(stream);
+    xp::View pv; xp::OutView ov;
+    size_t cb = (size_t)p->ncol * esize(p->dtype), fb = cb * (size_t)p->nlev;
+    const void *dt, *dp;
+    void *od;
+    if ((rc = stage_view(st, p, &pv)) || (rc = st.in(pt, cb, p->mem, &dt)) || (rc = st.in(pp, cb, p->mem, &dp)) ||
+        (rc = st.out(out, fb, p->mem, &od))) return rc;
+    ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
+    xp::Tables tb = g.tb;
+    int tm = moist_mode == XP_MOIST_TABLE;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_moist_lapse<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, ov);
+        else hipLaunchKernelGGL((xp::k_moist_lapse<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, ov);
+    }
+    return st.finish();
+}
+
+int xp_parcel_profile(const xp_view *p, const void *pp, const void *pt, const void *ptd, int32_t moist_mode,
+                      void *t_out, void *tv_out, void *lp, void *lt, void *ltv, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure"))) return rc;
+    if (!pp || !pt || !ptd) return fail(XP_E_ARG, "xp_parcel_profile: null parcel");
+    if (moist_mode == XP_MOIST_TABLE && !g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
+    Stager st(stream);
+    xp::View pv; xp::OutView ot, otv;
+    size_t cb = (size_t)p->ncol * esize(p->dtype), fb = cb * (size_t)p->nlev;
+    const void *dpp, *dpt, *dptd;
+    void *d1, *d2, *d3, *d4, *d5;
+    if ((rc = stage_view(st, p, &pv)) || (rc = st.in(pp, cb, p->mem, &dpp)) || (rc = st.in(pt, cb, p->mem, &dpt)) ||
+        (rc = st.in(ptd, cb, p->mem, &dptd)) || (rc = st.out(t_out, fb, p->mem, &d1)) || (rc = st.out(tv_out, fb, p->mem, &d2)) ||
+        (rc = st.out(lp, cb, p->mem, &d3)) || (rc = st.out(lt, cb, p->mem, &d4)) || (rc = st.out(ltv, cb, p->mem, &d5))) return rc;
+    ot.data = d1; ot.ls = p->lev_stride; ot.cs = p->col_stride;
+    otv.data = d2; otv.ls = p->lev_stride; otv.cs = p->col_stride;
+    xp::Tables tb = g.tb;
+    int tm = moist_mode == XP_MOIST_TABLE;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_parcel_profile<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, ot, otv, d3, d4, d5);
+        else hipLaunchKernelGGL((xp::k_parcel_profile<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, ot, otv, d3, d4, d5);
+    }
+    return st.finish();
+}
+
+int xp_lfc_el(const xp_view *p, const xp_view *par, const xp_view *env, const void *lcl_p, const void *lcl_t,
+              xp_scalars_out *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(par, "parcel_temperature")) || (rc = check_view(env, "temperature")) ||
+        (rc = same_shape(p, par, "pressure/parcel_temperature")) || (rc = same_shape(p, env, "pressure/temperature"))) return rc;
+    if (!lcl_p || !lcl_t || !out) return fail(XP_E_ARG, "xp_lfc_el: null argument");
+    Stager st(stream);
+    xp::View pv, pav, ev;
+    xp::ScalarsOut so;
+    size_t cb = (size_t)p->ncol * esize(p->dtype);
+    const void *dlp, *dlt;
+    if ((rc = stage_view(st, p, &pv)) || (rc = stage_view(st, par, &pav)) || (rc = stage_view(st, env, &ev)) ||
+        (rc = st.in(lcl_p, cb, p->mem, &dlp)) || (rc = st.in(lcl_t, cb, p->mem, &dlt)) ||
+        (rc = stage_scalars(st, out, p->ncol, &so))) return rc;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_lfc_el<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, pav, ev, p->nlev, p->ncol, dlp, dlt, so);
+        else hipLaunchKernelGGL((xp::k_lfc_el<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, pav, ev, p->nlev, p->ncol, dlp, dlt, so);
+    }
+    return st.finish();
+}
+
+int xp_cape_cin_base(const xp_view *p, const xp_view *env, const xp_view *par, const void *lfc_p, const void *el_p,
+                     const xp_opts *o, void *cape, void *cin, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(par, "parcel_temperature")) || (rc = check_view(env, "temperature")) ||
+        (rc = same_shape(p, par, "pressure/parcel_temperature")) || (rc = same_shape(p, env, "pressure/temperature"))) return rc;
+    if (!lfc_p || !el_p) return fail(XP_E_ARG, "xp_cape_cin_base: null argument");
+    Stager st(stream);
+    xp::View pv, pav, ev;
+    size_t cb = (size_t)p->ncol * esize(p->dtype);
+    const void *dl, *de;
+    void *dc, *dn;
+    if ((rc = stage_view(st, p, &pv)) || (rc = stage_view(st, par, &pav)) || (rc = stage_view(st, env, &ev)) ||
+        (rc = st.in(lfc_p, cb, p->mem, &dl)) || (rc = st.in(el_p, cb, p->mem, &de)) || (rc = st.out(cape, cb, p->mem, &dc)) ||
+        (rc = st.out(cin, cb, p->mem, &dn))) return rc;
+    int pn = o ? o->pos_cape_neg_cin : 1, pz = o ? o->post_zero_cin : 0;
+    if (p->ncol) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_cape_cin_base<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, ev, pav, p->nlev, p->ncol, dl, de, pn, pz, dc, dn);
+        else hipLaunchKernelGGL((xp::k_cape_cin_base<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, ev, pav, p->nlev, p->ncol, dl, de, pn, pz, dc, dn);
+    }
+    return st.finish();
+}
+
+}  // extern "C"

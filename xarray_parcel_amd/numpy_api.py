@@ -1,0 +1,379 @@
+"""
+Array-level host API over libxparcel: the reference's function names
+(modules/parcel_functions.py, "pf.py") on plain arrays.
+
+Inputs are NumPy arrays (host memory, staged through the library) or torch CUDA
+tensors (used in place, on torch's current stream), laid out (nlev, ...) with the
+vertical first: (nlev,), (nlev, ncol) or (nlev, ny, nx).  Per-column results come
+back with the horizontal shape of the input; profiles as (nlev+1, ...).  Returned
+containers are plain dicts -- the xarray-facing mirrors in parcel_functions.py
+wrap them into Datasets.
+
+There is no CPU path here: every function ends in a kernel launch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing (device memory, streams); the API also works without it on host arrays
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class _Arr:
+    """Uniform handle on a NumPy array or torch CUDA tensor, flattened to (nlev, ncol)."""
+
+    def __init__(self, x, dtype=None, like=None):
+        if _is_torch(x):
+            if not x.is_cuda:
+                x = x.cuda()
+            if dtype is not None:
+                x = x.to(dtype=torch.float64 if dtype == np.float64 else torch.float32)
+            elif x.dtype not in (torch.float32, torch.float64):
+                x = x.to(torch.float64)
+            self.t = x.contiguous()
+            self.dev = True
+            self.np_dtype = np.float64 if self.t.dtype == torch.float64 else np.float32
+            self.shape = tuple(self.t.shape)
+            self.ptr = self.t.data_ptr()
+        else:
+            a = np.asarray(x)
+            if dtype is not None:
+                a = a.astype(dtype, copy=False)
+            elif a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64)
+            self.a = np.ascontiguousarray(a)
+            self.dev = False
+            self.np_dtype = self.a.dtype.type
+            self.shape = self.a.shape
+            self.ptr = self.a.ctypes.data
+
+    @property
+    def xp_dtype(self):
+        return L.XP_F64 if self.np_dtype == np.float64 else L.XP_F32
+
+    @property
+    def mem(self):
+        return L.XP_MEM_DEVICE if self.dev else L.XP_MEM_HOST
+
+
+def _stream(dev):
+    if dev and torch is not None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(0)
+
+
+def _device_of(h):
+    if h.dev:
+        return h.t.device.index
+    return None
+
+
+def _common(*xs):
+    """Bring inputs to one dtype / one memory space; return handles + (nlev, ncol, hshape)."""
+    any_dev = any(_is_torch(x) and x.is_cuda for x in xs)
+    f64 = any((_is_torch(x) and x.dtype == torch.float64) or
+              (not _is_torch(x) and np.asarray(x).dtype != np.float32) for x in xs)
+    dt = np.float64 if f64 else np.float32
+    hs = []
+    for x in xs:
+        if any_dev and not _is_torch(x):
+            x = torch.as_tensor(np.asarray(x, dtype=dt)).cuda()
+        hs.append(_Arr(x, dtype=dt))
+    return hs, dt, any_dev
+
+
+def _view(h, nlev, ncol):
+    return L.View(h.ptr, h.xp_dtype, h.mem, nlev, ncol, ncol, 1)
+
+
+def _alloc(shape, np_dtype, dev, like=None):
+    if dev:
+        td = {np.float64: torch.float64, np.float32: torch.float32, np.int32: torch.int32}[np_dtype]
+        t = torch.empty(shape, dtype=td, device=like.t.device if like is not None else 'cuda')
+        return t, t.data_ptr()
+    a = np.empty(shape, dtype=np_dtype)
+    return a, a.ctypes.data
+
+
+def _vert_shape(h):
+    nlev = h.shape[0]
+    hshape = tuple(h.shape[1:])
+    ncol = int(np.prod(hshape)) if hshape else 1
+    return nlev, ncol, hshape
+
+
+def _per_col(x, ncol, dt, dev, like):
+    """Per-column input (scalar or array of hshape) -> handle of ncol elements."""
+    if _is_torch(x):
+        h = _Arr(x.reshape(-1), dtype=dt)
+    else:
+        a = np.asarray(x, dtype=dt).reshape(-1)
+        if a.size == 1 and ncol != 1:
+            a = np.full(ncol, a[0], dtype=dt)
+        h = _Arr(torch.as_tensor(a).to(like.t.device) if dev else a, dtype=dt)
+    assert int(np.prod(h.shape)) == ncol, 'per-column argument does not match the grid'
+    return h
+
+
+def _opts(virtual_temperature_correction=True, lcl_interp='log', pos_cape_neg_cin=True, post_zero_cin=False,
+          moist='exact'):
+    if lcl_interp not in L.LCL_INTERP:
+        raise AssertionError('interpolator must be linear or log')          # pf.py:878
+    return L.Opts(int(bool(virtual_temperature_correction)), L.LCL_INTERP[lcl_interp], int(bool(pos_cape_neg_cin)),
+                  int(bool(post_zero_cin)), L.MOIST[moist], L.XP_F64, (C.c_int32 * 2)(0, 0))
+
+
+_DEFAULT = {'moist': 'exact'}
+
+
+def set_moist_lapse(mode):
+    """'exact' (RK4 integration of MetPy's ODE) or 'table' (the reference's lookup tables; needs
+    adiabat_tables.load_moist_adiabat_lookups())."""
+    assert mode in L.MOIST
+    _DEFAULT['moist'] = mode
+
+
+def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=None, parcel_values=None,
+                     want_profile=False, want=None, moist=None, **kwargs):
+    """pf.py:1394-1475 with the three drivers.  Returns a dict of per-column arrays (and 'profile')."""
+    (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
+    assert p.shape == t.shape == td.shape, 'pressure, temperature, dewpoint must share a shape'
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    o = _opts(moist=moist or _DEFAULT['moist'], **kwargs)
+    if depth is None:
+        depth = 300.0 if parcel == 'most_unstable' else 100.0                # pf.py:1558, 1652
+    pc = L.Parcel(L.PARCEL[parcel], 0, float(depth), None, None, None)
+    keep = []
+    if parcel == 'explicit':
+        hs = [_per_col(x, ncol, dt, dev, p) for x in parcel_values]
+        keep += hs
+        pc.pressure, pc.temperature, pc.dewpoint = hs[0].ptr, hs[1].ptr, hs[2].ptr
+    names = L.SCALAR_F + L.SCALAR_I + L.SCALAR_P if want is None else tuple(want)
+    so = L.ScalarsOut()
+    so.dtype = p.xp_dtype
+    so.mem = p.mem
+    out = {}
+    for k in names:
+        arr, ptr = _alloc((ncol,), np.int32 if k in L.SCALAR_I else dt, dev, p)
+        setattr(so, k, ptr)
+        out[k] = arr
+    po = None
+    if want_profile:
+        po = L.ProfileOut()
+        po.dtype, po.mem, po.nlev_out, po.lev_stride, po.col_stride = p.xp_dtype, p.mem, nlev + 1, ncol, 1
+        prof = {}
+        for k in L.PROFILE_VARS:
+            arr, ptr = _alloc((nlev + 1, ncol), dt, dev, p)
+            setattr(po, k, ptr)
+            prof[k] = arr
+    L.check(lib.xp_cape_cin(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)),
+                            C.byref(_view(td, nlev, ncol)), C.byref(pc), C.byref(o), C.byref(so),
+                            C.byref(po) if po is not None else None, _stream(dev)))
+    res = {k: v.reshape(hshape) for k, v in out.items()}
+    if want_profile:
+        res['profile'] = {k: v.reshape((nlev + 1,) + hshape) for k, v in prof.items()}
+    return res
+
+
+# ---- reference-named functions (one column or a grid) -----------------------------------------
+def _split(res):
+    cc = {'cape': res['cape'], 'cin': res['cin']}
+    prof = dict(res.get('profile', {}))
+    for k in ('lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature', 'lfc_pressure', 'lfc_temperature',
+              'el_pressure', 'el_temperature', 'lfc_index', 'el_index', 'status'):
+        prof[k] = res[k]
+    return cc, prof
+
+
+def cape_cin(pressure, temperature, dewpoint, parcel_temperature, parcel_pressure, parcel_dewpoint, **kwargs):
+    """pf.py:1394."""
+    return _split(cape_cin_columns(pressure, temperature, dewpoint, parcel='explicit',
+                                   parcel_values=(parcel_pressure, parcel_temperature, parcel_dewpoint),
+                                   want_profile=True, **kwargs))
+
+
+def surface_based_cape_cin(pressure, temperature, dewpoint, **kwargs):
+    """pf.py:1477."""
+    return _split(cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', want_profile=True, **kwargs))
+
+
+def most_unstable_cape_cin(pressure, temperature, dewpoint, depth=300, **kwargs):
+    """pf.py:1557."""
+    res = cape_cin_columns(pressure, temperature, dewpoint, parcel='most_unstable', depth=depth, want_profile=True,
+                           **kwargs)
+    cc, prof = _split(res)
+    return cc, prof, {'pressure': res['parcel_pressure'], 'temperature': res['parcel_temperature'],
+                      'dewpoint': res['parcel_dewpoint'], 'index': res['parcel_index']}
+
+
+def mixed_layer_cape_cin(pressure, temperature, dewpoint, depth=100, **kwargs):
+    """pf.py:1651."""
+    res = cape_cin_columns(pressure, temperature, dewpoint, parcel='mixed_layer', depth=depth, want_profile=True,
+                           **kwargs)
+    cc, prof = _split(res)
+    return cc, prof, {'pressure': res['parcel_pressure'], 'temperature': res['parcel_temperature'],
+                      'dewpoint': res['parcel_dewpoint']}
+
+
+def parcel_profile_with_lcl(pressure, temperature, dewpoint, parcel_pressure, parcel_temperature, parcel_dewpoint,
+                            lcl_interp='log', moist=None):
+    """pf.py:806."""
+    res = cape_cin_columns(pressure, temperature, dewpoint, parcel='explicit',
+                           parcel_values=(parcel_pressure, parcel_temperature, parcel_dewpoint), want_profile=True,
+                           lcl_interp=lcl_interp, moist=moist,
+                           want=('lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature'))
+    out = dict(res['profile'])
+    for k in ('lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature'):
+        out[k] = res[k]
+    return out
+
+
+def _select(pressure, temperature, dewpoint, mode, depth):
+    (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    pc = L.Parcel(L.PARCEL[mode], 0, float(depth), None, None, None)
+    so = L.ScalarsOut()
+    so.dtype, so.mem = p.xp_dtype, p.mem
+    out = {}
+    for k in L.SCALAR_P + ('parcel_index',):
+        arr, ptr = _alloc((ncol,), np.int32 if k == 'parcel_index' else dt, dev, p)
+        setattr(so, k, ptr)
+        out[k] = arr
+    L.check(lib.xp_select_parcel(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)),
+                                 C.byref(_view(td, nlev, ncol)), C.byref(pc), C.byref(so), _stream(dev)))
+    return {'pressure': out['parcel_pressure'].reshape(hshape), 'temperature': out['parcel_temperature'].reshape(hshape),
+            'dewpoint': out['parcel_dewpoint'].reshape(hshape), 'index': out['parcel_index'].reshape(hshape)}
+
+
+def most_unstable_parcel(pressure, temperature, dewpoint, depth=300):
+    """pf.py:102."""
+    return _select(pressure, temperature, dewpoint, 'most_unstable', depth)
+
+
+def mixed_parcel(pressure, temperature, dewpoint, depth=100):
+    """pf.py:229."""
+    r = _select(pressure, temperature, dewpoint, 'mixed_layer', depth)
+    r.pop('index')
+    return r
+
+
+def mixed_layer(dat, depth=100):
+    """pf.py:137: dat = dict with 'pressure' and variables to mix."""
+    out = {}
+    for k, v in dat.items():
+        if k == 'pressure':
+            continue
+        (p, x), dt, dev = _common(dat['pressure'], v)
+        nlev, ncol, hshape = _vert_shape(p)
+        lib = L.init(_device_of(p))
+        arr, ptr = _alloc((ncol,), dt, dev, p)
+        L.check(lib.xp_mixed_layer(C.byref(_view(p, nlev, ncol)), C.byref(_view(x, nlev, ncol)), C.c_double(depth),
+                                   C.c_void_p(ptr), _stream(dev)))
+        out[k] = arr.reshape(hshape)
+    return out
+
+
+def lcl(parcel_pressure, parcel_temperature, parcel_dewpoint):
+    """pf.py:609."""
+    (p, t, td), dt, dev = _common(*(x if _is_torch(x) else np.atleast_1d(np.asarray(x, dtype=np.float64))
+                                    for x in (parcel_pressure, parcel_temperature, parcel_dewpoint)))
+    n = int(np.prod(p.shape))
+    shape = tuple(p.shape) if np.ndim(parcel_pressure) else ()
+    lib = L.init(_device_of(p))
+    outs = [_alloc((n,), dt, dev, p) for _ in range(3)]
+    st, stp = _alloc((n,), np.int32, dev, p)
+    L.check(lib.xp_lcl(C.c_int64(n), p.xp_dtype, p.mem, C.c_void_p(p.ptr), C.c_void_p(t.ptr), C.c_void_p(td.ptr),
+                       C.c_void_p(outs[0][1]), C.c_void_p(outs[1][1]), C.c_void_p(outs[2][1]), C.c_void_p(stp),
+                       _stream(dev)))
+    return {'lcl_pressure': outs[0][0].reshape(shape), 'lcl_temperature': outs[1][0].reshape(shape),
+            'lcl_virtual_temperature': outs[2][0].reshape(shape)}
+
+
+def _lapse(fn_name, pressure, parcel_temperature, parcel_pressure, moist_mode=None):
+    (p,), dt, dev = _common(pressure)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    pt = _per_col(parcel_temperature, ncol, dt, dev, p)
+    pp = _per_col(parcel_pressure, ncol, dt, dev, p) if parcel_pressure is not None else None
+    out, optr = _alloc((nlev, ncol), dt, dev, p)
+    args = [C.byref(_view(p, nlev, ncol)), C.c_void_p(pt.ptr), C.c_void_p(pp.ptr) if pp is not None else None]
+    if moist_mode is not None:
+        args.append(C.c_int32(moist_mode))
+    args += [C.c_void_p(optr), _stream(dev)]
+    L.check(getattr(lib, fn_name)(*args))
+    return out.reshape((nlev,) + hshape)
+
+
+def dry_lapse(pressure, parcel_temperature, parcel_pressure=None):
+    """pf.py:291."""
+    return _lapse('xp_dry_lapse', pressure, parcel_temperature, parcel_pressure)
+
+
+def moist_lapse(pressure, parcel_temperature, parcel_pressure=None, moist=None):
+    """pf.py:525."""
+    return _lapse('xp_moist_lapse', pressure, parcel_temperature, parcel_pressure,
+                  moist_mode=L.MOIST[moist or _DEFAULT['moist']])
+
+
+def parcel_profile(pressure, parcel_pressure, parcel_temperature, parcel_dewpoint, moist=None):
+    """pf.py:712."""
+    (p,), dt, dev = _common(pressure)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    pp, pt, ptd = (_per_col(x, ncol, dt, dev, p) for x in (parcel_pressure, parcel_temperature, parcel_dewpoint))
+    t_out, tptr = _alloc((nlev, ncol), dt, dev, p)
+    tv_out, tvptr = _alloc((nlev, ncol), dt, dev, p)
+    ls = [_alloc((ncol,), dt, dev, p) for _ in range(3)]
+    L.check(lib.xp_parcel_profile(C.byref(_view(p, nlev, ncol)), C.c_void_p(pp.ptr), C.c_void_p(pt.ptr),
+                                  C.c_void_p(ptd.ptr), C.c_int32(L.MOIST[moist or _DEFAULT['moist']]),
+                                  C.c_void_p(tptr), C.c_void_p(tvptr), C.c_void_p(ls[0][1]), C.c_void_p(ls[1][1]),
+                                  C.c_void_p(ls[2][1]), _stream(dev)))
+    pres = p.t if dev else p.a
+    return {'pressure': pres, 'temperature': t_out.reshape((nlev,) + hshape),
+            'virtual_temperature': tv_out.reshape((nlev,) + hshape), 'lcl_pressure': ls[0][0].reshape(hshape),
+            'lcl_temperature': ls[1][0].reshape(hshape), 'lcl_virtual_temperature': ls[2][0].reshape(hshape)}
+
+
+def lfc_el(pressure, parcel_temperature, temperature, lcl_pressure, lcl_temperature):
+    """pf.py:1066."""
+    (p, par, env), dt, dev = _common(pressure, parcel_temperature, temperature)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    lp, lt = (_per_col(x, ncol, dt, dev, p) for x in (lcl_pressure, lcl_temperature))
+    so = L.ScalarsOut()
+    so.dtype, so.mem = p.xp_dtype, p.mem
+    out = {}
+    for k in ('lfc_pressure', 'lfc_temperature', 'el_pressure', 'el_temperature', 'lfc_index', 'el_index', 'status'):
+        arr, ptr = _alloc((ncol,), np.int32 if k in L.SCALAR_I else dt, dev, p)
+        setattr(so, k, ptr)
+        out[k] = arr.reshape(hshape)
+    L.check(lib.xp_lfc_el(C.byref(_view(p, nlev, ncol)), C.byref(_view(par, nlev, ncol)),
+                          C.byref(_view(env, nlev, ncol)), C.c_void_p(lp.ptr), C.c_void_p(lt.ptr), C.byref(so),
+                          _stream(dev)))
+    return out
+
+
+def cape_cin_base(pressure, temperature, lfc_pressure, el_pressure, parcel_temperature, pos_cape_neg_cin=True,
+                  post_zero_cin=False, **_ignored):
+    """pf.py:1291."""
+    (p, env, par), dt, dev = _common(pressure, temperature, parcel_temperature)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    lf, el = (_per_col(x, ncol, dt, dev, p) for x in (lfc_pressure, el_pressure))
+    o = _opts(pos_cape_neg_cin=pos_cape_neg_cin, post_zero_cin=post_zero_cin)
+    cape, cptr = _alloc((ncol,), dt, dev, p)
+    cin, nptr = _alloc((ncol,), dt, dev, p)
+    L.check(lib.xp_cape_cin_base(C.byref(_view(p, nlev, ncol)), C.byref(_view(env, nlev, ncol)),
+                                 C.byref(_view(par, nlev, ncol)), C.c_void_p(lf.ptr), C.c_void_p(el.ptr), C.byref(o),
+                                 C.c_void_p(cptr), C.c_void_p(nptr), _stream(dev)))
+    return {'cape': cape.reshape(hshape), 'cin': cin.reshape(hshape)}
