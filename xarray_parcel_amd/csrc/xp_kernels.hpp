@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     };
     auto source = [&](double P, double T_, double Td_) {
         double X = log(P);
+        if (isnan_(P) && !lcl_done && !lcl_nan) status |= 4;               // NaN pressure below the LCL (see xparcel.h)
         if (!lcl_done && !lcl_nan && P < l.p) emit_lcl(P, X, T_, Td_);
         double tp, w;
         if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         if (lcl_nan) { P = X = tp = tvp = T_ = tve = Td_ = qnan(); }       // NaN LCL blanks the whole profile (pf.py:965-985)
         emit(P, X, tp, tvp, T_, tve, Td_, false);
         if (!isnan_(P) && !lcl_done) { pb = P; xb = X; tb_ = T_; tdb = Td_; }
-        else if (isnan_(P) && !lcl_done) status |= 4;
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
