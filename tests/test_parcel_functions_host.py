@@ -1,0 +1,107 @@
+"""Host logic of the xarray-facing mirror (xarray_parcel_amd/parcel_functions.py): DataArray plumbing,
+attrs, prefixes, assert messages, MU/ML profile trimming.  CPU part: the kernel call is replaced by a
+stand-in built on the oracle (there is no CPU product path); GPU part: the same calls for real."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests import kat_recipes as kr
+from xarray_parcel_amd import parcel_functions as pf
+from xarray_parcel_amd._xr import DataArray, Dataset
+
+VD = 'model_level_number'
+
+
+def _da(x, name=None):
+    x = np.asarray(x, dtype=np.float64)
+    return DataArray(x, dims=(VD,), coords={VD: np.arange(1, len(x) + 1)}, attrs={'units': 'K'}, name=name)
+
+
+def _stand_in(p, t, td, parcel='surface', depth=None, parcel_values=None, want_profile=False, want=None, moist=None,
+              **kw):
+    sh = p.shape[1:]
+    f = lambda a: np.asarray(a, dtype=np.float64).reshape(p.shape[0], -1)
+    pv = None if parcel_values is None else np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1),
+                                                                      (f(p).shape[1],)) for v in parcel_values])
+    r = co.cape_cin_grid(f(p), f(t), f(td), parcel=parcel, depth=depth, parcel_values=pv, want_profile=True,
+                         moist='rk4', **kw)
+    out = {k: (v.reshape(sh) if k != 'profile' else {kk: vv.reshape((vv.shape[0],) + sh) for kk, vv in v.items()})
+           for k, v in r.items()}
+    for k in ('parcel_pressure', 'parcel_temperature', 'parcel_dewpoint'):
+        out[k] = np.full(sh, np.nan)
+    return out
+
+
+@pytest.fixture
+def stub(monkeypatch):
+    monkeypatch.setattr(pf._api, 'cape_cin_columns', _stand_in)
+
+
+def test_surface_based_structure_attrs_prefix(stub):
+    i = kr.inputs('test_surface_based_cape_cin')
+    p, t, td = _da(i['levels']), _da(i['temperatures']), _da(i['dewpoints'])
+    res, prof = pf.surface_based_cape_cin(p, t, td)
+    assert abs(float(res.cape.values) - 230.1982) < 0.015 and abs(float(res.cin.values) + 58.0673) < 0.015
+    assert res.cape.attrs['units'] == 'J kg$^{-1}$' and res.cape.attrs['description'] == 'CAPE for surface-based parcel.'
+    assert res.attrs['correction'].startswith('Virtual temperature correction used')
+    assert prof.pressure.dims == (VD,) and prof.pressure.shape == (len(i['levels']) + 1,)
+    assert set(('lfc_pressure', 'el_pressure', 'lcl_pressure', 'environment_virtual_temperature')) <= set(prof.keys())
+    res2, _ = pf.surface_based_cape_cin(p, t, td, prefix='sb', virtual_temperature_correction=False,
+                                        lcl_interp='linear')
+    assert 'sb_cape' in res2 and abs(float(res2.sb_cape.values) - 75.0535) < 0.015
+    assert res2.attrs['correction'].startswith('Virtual temperature correction not used')
+
+
+def test_grid_dims_are_preserved(stub):
+    from xarray_parcel_amd import synth
+    p, t, td = synth.columns(20, 12, seed=2)
+    mk = lambda a: DataArray(a.reshape(20, 3, 4).transpose(1, 0, 2), dims=('lat', VD, 'lon'),
+                             coords={'lat': [1., 2., 3.], VD: np.arange(20), 'lon': [5., 6., 7., 8.]})
+    res, prof = pf.surface_based_cape_cin(mk(p), mk(t), mk(td))
+    assert res.cape.dims == ('lat', 'lon') and res.cape.shape == (3, 4)
+    assert prof.temperature.dims == (VD, 'lat', 'lon') and prof.temperature.shape == (21, 3, 4)
+    ref = co.cape_cin_grid(p, t, td, moist='rk4')
+    assert np.allclose(res.cape.values.reshape(-1), ref['cape'])
+
+
+def test_reference_asserts(stub):
+    i = kr.inputs('test_surface_based_cape_cin')
+    p, t, td = _da(i['levels']), _da(i['temperatures']), _da(i['dewpoints'])
+    with pytest.raises(AssertionError, match='Pressure requires name pressure.'):
+        pf.most_unstable_cape_cin(p, t, td)
+    bad = DataArray(i['levels'], dims=(VD,), coords={VD: np.arange(len(i['levels'])) * 2})
+    with pytest.raises(AssertionError, match='increments must all be 1'):
+        pf.surface_based_cape_cin(bad, t, td)
+
+
+def test_mu_profile_is_trimmed(stub):
+    i = kr.inputs('test_most_unstable_parcel')
+    res, prof, layer = pf.most_unstable_cape_cin(_da(i['levels'], 'pressure'), _da(i['temperatures'], 'temperature'),
+                                                 _da(i['dewpoints'], 'dewpoint'), depth=100)
+    assert prof.pressure.shape[0] == 3            # MU level 1 of 3 -> 2 levels + LCL
+    assert res.cape.attrs['description'] == 'CAPE for most-unstable parcel in lowest 100 hPa.'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['test_surface_based_cape_cin', 'test_surface_based_cape_cin_mp',
+                                  'test_sensitive_sounding', 'test_cape_cin_value_error'])
+def test_mirror_on_gpu(name):
+    i = kr.inputs(name)
+    kw = kr.MP if name.endswith('_mp') or name == 'test_cape_cin_value_error' else {}
+    res, prof = pf.surface_based_cape_cin(_da(i['levels']), _da(i['temperatures']), _da(i['dewpoints']), **kw)
+    exp = {w: v for w, v, _ in kr.expected(name)}
+    assert abs(float(res.cape.values) - exp['cape_cin.cape']) < 0.015
+    assert abs(float(res.cin.values) - exp['cape_cin.cin']) < 0.015
+
+
+@pytest.mark.gpu
+def test_mirror_mu_ml_on_gpu():
+    i = kr.inputs('test_mixed_layer_cape_cin')
+    args = (_da(i['levels'], 'pressure'), _da(i['temperatures'], 'temperature'), _da(i['dewpoints'], 'dewpoint'))
+    res, prof, mp = pf.mixed_layer_cape_cin(*args, **kr.MP)
+    assert abs(float(res.cape.values) - 1096.7461) < 0.015 and abs(float(res.cin.values) + 20.6727) < 0.015
+    assert abs(float(mp.pressure.values) - i['levels'][0]) < 1e-9
+    res, prof, layer = pf.most_unstable_cape_cin(*args, depth=300)
+    assert np.isfinite(float(res.cape.values))
+    lay = pf.most_unstable_parcel(Dataset(dict(pressure=args[0], temperature=args[1], dewpoint=args[2])))
+    assert float(lay.pressure.values) == float(layer.pressure.values)

@@ -1,0 +1,314 @@
+"""
+xarray-facing mirror of the hot path of traupach/xarray_parcel's modules/parcel_functions.py ("pf.py").
+
+Same function names, argument names, defaults, return structure, attrs and assert messages as the
+reference; the bodies hand the arrays to libxparcel (HIP, MI355X) through numpy_api.  Only the path named by
+BASELINE.json is here: the drivers, the column algorithms they use, and the table loader.  DataArrays may be
+xarray's (when installed) or the small stand-in of _xr.py.
+
+Arrays are moved to (vert_dim, ...) order, flattened to columns and sent to the GPU; dask-backed inputs are
+loaded by `.values` (the vertical must be one chunk in the reference too, pf.py:564).
+"""
+import numpy as np
+
+from . import numpy_api as _api
+from ._lib import XParcelError
+from ._xr import DataArray, Dataset, merge
+
+VERT = 'model_level_number'
+
+
+# -- DataArray plumbing ---------------------------------------------------------------------------
+def _split(x, vert_dim):
+    """-> (values with vert_dim first, horizontal dims, horizontal coords, vertical coordinate)."""
+    if not isinstance(x, DataArray):
+        return np.asarray(x, dtype=np.float64), (), {}, None
+    if vert_dim in x.dims:
+        other = tuple(d for d in x.dims if d != vert_dim)
+        xt = x.transpose(vert_dim, *other)
+        vc = np.asarray(x.coords[vert_dim]) if vert_dim in x.coords else np.arange(x.shape[x.dims.index(vert_dim)])
+    else:
+        other, xt, vc = tuple(x.dims), x, None
+    coords = {k: np.asarray(v) for k, v in x.coords.items() if k in other}
+    return np.asarray(xt.values), other, coords, vc
+
+
+def _check_index(vc, msg):
+    if vc is not None and len(vc) > 1:
+        assert np.all(np.abs(np.diff(vc)) == 1), msg
+
+
+def _horiz(values, dims, coords, attrs=None, name=None):
+    return DataArray(np.asarray(values), dims=dims, coords={k: v for k, v in coords.items() if k in dims},
+                     attrs=attrs or {}, name=name)
+
+
+def _vert(values, vert_dim, vcoord, dims, coords, attrs=None, name=None):
+    c = {k: v for k, v in coords.items() if k in dims}
+    c[vert_dim] = vcoord
+    return DataArray(np.asarray(values), dims=(vert_dim,) + tuple(dims), coords=c, attrs=attrs or {}, name=name)
+
+
+def _np(x):
+    return x.cpu().numpy() if hasattr(x, 'cpu') else np.asarray(x)
+
+
+_ATTRS = {
+    'cape': {'long_name': 'Convective available potential energy', 'units': 'J kg$^{-1}$'},       # pf.py:1366-1368
+    'cin': {'long_name': 'Convective inhibition', 'units': 'J kg$^{-1}$'},                          # pf.py:1383-1385
+    'lcl_pressure': {'long_name': 'Lifting condensation level pressure', 'units': 'hPa'},            # pf.py:669-677
+    'lcl_temperature': {'long_name': 'Lifting condensation level temperature', 'units': 'K'},
+    'lcl_virtual_temperature': {'long_name': 'Lifting condensation level virtual temperature', 'units': 'K'},
+    'el_pressure': {'long_name': 'Equilibrium level pressure', 'units': 'hPa'},                      # pf.py:1188-1196
+    'el_temperature': {'long_name': 'Equilibrium level temperature', 'units': 'K'},
+    'lfc_pressure': {'long_name': 'Level of free convection pressure', 'units': 'hPa'},
+    'lfc_temperature': {'long_name': 'Level of free convection temperature', 'units': 'K'},
+    'pressure': {'long_name': 'Pressure at LCL'},                                                    # pf.py:889-890 (sic)
+    'temperature': {'long_name': 'Temperature at LCL', 'units': 'K'},
+    'virtual_temperature': {'long_name': 'Virtual temperature', 'units': 'K'},
+    'environment_temperature': {'long_name': 'Environment temperature', 'units': 'K'},               # pf.py:849-852
+    'environment_dewpoint': {'long_name': 'Environment dewpoint', 'units': 'K'},
+    'environment_virtual_temperature': {'long_name': 'Virtual temperature', 'units': 'K'},
+}
+_PROFILE_KEYS = ('pressure', 'temperature', 'virtual_temperature', 'environment_temperature',
+                 'environment_virtual_temperature', 'environment_dewpoint')
+_LFC_KEYS = ('lfc_pressure', 'lfc_temperature', 'el_pressure', 'el_temperature')
+_LCL_KEYS = ('lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature')
+
+
+def _raise_like_reference(e):
+    if isinstance(e, XParcelError) and e.code == -3:
+        raise AssertionError('Call load_moist_adiabat_lookups first.') from e           # pf.py:60
+    raise e
+
+
+def _run(pressure, temperature, dewpoint, vert_dim, parcel, depth=None, parcel_values=None, trim=False, **kwargs):
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    t, _, _, _ = _split(temperature, vert_dim)
+    td, _, _, _ = _split(dewpoint, vert_dim)
+    _check_index(vc, 'Vert_dim index increments must all be 1.')                        # pf.py:957
+    try:
+        res = _api.cape_cin_columns(p, t, td, parcel=parcel, depth=depth, parcel_values=parcel_values,
+                                    want_profile=True, **kwargs)
+    except XParcelError as e:
+        _raise_like_reference(e)
+    vtc = kwargs.get('virtual_temperature_correction', True)
+    cc = Dataset({k: _horiz(_np(res[k]), dims, coords, attrs=dict(_ATTRS[k]), name=k) for k in ('cape', 'cin')})
+    cc.attrs = {'correction': ('Virtual temperature correction used in CAPE/CIN calculations.' if vtc else
+                               'Virtual temperature correction not used in CAPE/CIN calculations.')}  # pf.py:1453, 1472
+    prof_np = {k: _np(res['profile'][k]) for k in _PROFILE_KEYS}
+    nrow = prof_np['pressure'].shape[0]
+    if trim:
+        # the reference drops levels that are NaN in every column (pf.py:1552, 1637): trim the NaN padding
+        while nrow > 1 and np.all(np.isnan(prof_np['pressure'][nrow - 1])):
+            nrow -= 1
+    vcoord = np.arange(nrow) + (vc[0] if vc is not None else 0)    # re-indexed vertical coordinate (pf.py:875)
+    profile = Dataset()
+    for k in _PROFILE_KEYS:
+        profile[k] = _vert(prof_np[k][:nrow], vert_dim, vcoord, dims, coords, attrs=dict(_ATTRS[k]), name=k)
+    for k in _LCL_KEYS + _LFC_KEYS:
+        profile[k] = _horiz(_np(res[k]), dims, coords, attrs=dict(_ATTRS[k]), name=k)
+    extra = {k: _horiz(_np(res[k]), dims, coords, name=k) for k in
+             ('parcel_pressure', 'parcel_temperature', 'parcel_dewpoint', 'parcel_index', 'lfc_index', 'el_index',
+              'status')}
+    return cc, profile, extra
+
+
+def _prefix(res, prefix):
+    if prefix is not None:
+        res = res.rename({'cape': prefix + '_cape', 'cin': prefix + '_cin'})              # pf.py:1510-1512
+    return res
+
+
+# -- drivers ------------------------------------------------------------------------------------------
+def cape_cin(pressure, temperature, dewpoint, parcel_temperature, parcel_pressure, parcel_dewpoint,
+             vert_dim=VERT, virtual_temperature_correction=True, lcl_interp='log', **kwargs):
+    """pf.py:1394.  Returns (Dataset{cape, cin}, profile Dataset merged with LFC/EL)."""
+    pv = tuple(np.asarray(getattr(x, 'values', x), dtype=np.float64)
+               for x in (parcel_pressure, parcel_temperature, parcel_dewpoint))
+    cc, profile, _ = _run(pressure, temperature, dewpoint, vert_dim, 'explicit', parcel_values=pv,
+                          virtual_temperature_correction=virtual_temperature_correction, lcl_interp=lcl_interp,
+                          **kwargs)
+    return cc, profile
+
+
+def surface_based_cape_cin(pressure, temperature, dewpoint, vert_dim=VERT, prefix=None, **kwargs):
+    """pf.py:1477."""
+    res, profile, _ = _run(pressure, temperature, dewpoint, vert_dim, 'surface', **kwargs)
+    res.cape.attrs['description'] = 'CAPE for surface-based parcel.'                   # pf.py:1508-1509
+    res.cin.attrs['description'] = 'CIN for surface-based parcel.'
+    return _prefix(res, prefix), profile
+
+
+def _named(pressure, temperature, dewpoint):
+    assert getattr(pressure, 'name', None) == 'pressure', 'Pressure requires name pressure.'              # pf.py:1538
+    assert getattr(temperature, 'name', None) == 'temperature', 'Temperature requires name temperature.'   # pf.py:1539
+    assert getattr(dewpoint, 'name', None) == 'dewpoint', 'Dewpoint requires name dewpoint.'              # pf.py:1541
+
+
+def _parcel_ds(extra, long_names):
+    ds = Dataset()
+    for k, ln in long_names.items():
+        da = extra['parcel_' + k]
+        ds[k] = DataArray(da.values, dims=da.dims, coords=da.coords, attrs={'long_name': ln}, name=k)
+    return ds
+
+
+def most_unstable_cape_cin(pressure, temperature, dewpoint, vert_dim=VERT, depth=300, prefix=None, **kwargs):
+    """pf.py:1557.  Returns (cape/cin, profile, most-unstable parcel)."""
+    _named(pressure, temperature, dewpoint)
+    res, profile, extra = _run(pressure, temperature, dewpoint, vert_dim, 'most_unstable', depth=depth, trim=True,
+                               **kwargs)
+    desc = f'most-unstable parcel in lowest {depth} hPa.'
+    res.cape.attrs['description'] = f'CAPE for {desc}'
+    res.cin.attrs['description'] = f'CIN for {desc}'
+    layer = _parcel_ds(extra, {'pressure': 'Pressure', 'temperature': 'Temperature', 'dewpoint': 'Dewpoint'})
+    return _prefix(res, prefix), profile, layer
+
+
+def mixed_layer_cape_cin(pressure, temperature, dewpoint, vert_dim=VERT, depth=100, prefix=None, **kwargs):
+    """pf.py:1651.  Returns (cape/cin, profile, mixed parcel)."""
+    _named(pressure, temperature, dewpoint)
+    res, profile, extra = _run(pressure, temperature, dewpoint, vert_dim, 'mixed_layer', depth=depth, trim=True,
+                               **kwargs)
+    desc = f'fully-mixed lowest {depth} hPa parcel'
+    res.cape.attrs['description'] = f'CAPE for {desc}.'
+    res.cin.attrs['description'] = f'CIN for {desc}'
+    mp = _parcel_ds(extra, {'pressure': 'Pressure', 'temperature': 'Mixed parcel temperature',
+                            'dewpoint': 'Mixed-parcel dewpoint'})
+    mp.temperature.attrs['units'] = 'K'
+    return _prefix(res, prefix), profile, mp
+
+
+# -- column algorithms -----------------------------------------------------------------------------------
+def lcl(parcel_pressure, parcel_temperature, parcel_dewpoint):
+    """pf.py:609.  Dataset with lcl_pressure, lcl_temperature, lcl_virtual_temperature."""
+    p, dims, coords, _ = _split(parcel_pressure, None)
+    t, _, _, _ = _split(parcel_temperature, None)
+    td, _, _, _ = _split(parcel_dewpoint, None)
+    p, t, td = np.broadcast_arrays(p, t, td)
+    r = _api.lcl(p, t, td)
+    return Dataset({k: _horiz(_np(r[k]).reshape(p.shape), dims, coords, attrs=dict(_ATTRS[k]), name=k)
+                    for k in _LCL_KEYS})
+
+
+def dry_lapse(pressure, parcel_temperature, parcel_pressure=None, vert_dim=VERT):
+    """pf.py:291."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    pt = np.asarray(getattr(parcel_temperature, 'values', parcel_temperature), dtype=np.float64)
+    pp = None if parcel_pressure is None else np.asarray(getattr(parcel_pressure, 'values', parcel_pressure))
+    out = _np(_api.dry_lapse(p, pt, pp))
+    return _vert(out, vert_dim, vc, dims, coords, attrs={'long_name': 'Dry lapse rate temperature', 'units': 'K'})
+
+
+def moist_lapse(pressure, parcel_temperature, parcel_pressure=None, vert_dim=VERT, persist=True, moist=None):
+    """pf.py:525.  `moist='table'` (after load_moist_adiabat_lookups) reproduces the reference's lookup;
+    the default is the exact ODE."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    pt = np.asarray(getattr(parcel_temperature, 'values', parcel_temperature), dtype=np.float64)
+    pp = None if parcel_pressure is None else np.asarray(getattr(parcel_pressure, 'values', parcel_pressure))
+    try:
+        out = _np(_api.moist_lapse(p, pt, pp, moist=moist))
+    except XParcelError as e:
+        _raise_like_reference(e)
+    return _vert(out, vert_dim, vc, dims, coords, attrs={'long_name': 'Moist lapse rate temperature', 'units': 'K'})
+
+
+def parcel_profile(pressure, parcel_pressure, parcel_temperature, parcel_dewpoint, vert_dim=VERT):
+    """pf.py:712."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    pv = [np.asarray(getattr(x, 'values', x), dtype=np.float64) for x in
+          (parcel_pressure, parcel_temperature, parcel_dewpoint)]
+    r = _api.parcel_profile(p, *pv)
+    out = Dataset()
+    out['pressure'] = _vert(p, vert_dim, vc, dims, coords, name='pressure')
+    out['temperature'] = _vert(_np(r['temperature']), vert_dim, vc, dims, coords,
+                               attrs={'long_name': 'Lifted parcel temperature', 'units': 'K'}, name='temperature')
+    out['virtual_temperature'] = _vert(_np(r['virtual_temperature']), vert_dim, vc, dims, coords,
+                                       attrs=dict(_ATTRS['virtual_temperature']), name='virtual_temperature')
+    for k in _LCL_KEYS:
+        out[k] = _horiz(_np(r[k]), dims, coords, attrs=dict(_ATTRS[k]), name=k)
+    return out
+
+
+def parcel_profile_with_lcl(pressure, temperature, dewpoint, parcel_pressure, parcel_temperature, parcel_dewpoint,
+                            vert_dim=VERT, lcl_interp='log'):
+    """pf.py:806."""
+    pv = tuple(np.asarray(getattr(x, 'values', x), dtype=np.float64)
+               for x in (parcel_pressure, parcel_temperature, parcel_dewpoint))
+    _, profile, _ = _run(pressure, temperature, dewpoint, vert_dim, 'explicit', parcel_values=pv,
+                         lcl_interp=lcl_interp)
+    return Dataset({k: profile[k] for k in _PROFILE_KEYS + _LCL_KEYS})
+
+
+def lfc_el(pressure, parcel_temperature, temperature, lcl_pressure, lcl_temperature, vert_dim=VERT):
+    """pf.py:1066."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    par, _, _, _ = _split(parcel_temperature, vert_dim)
+    env, _, _, _ = _split(temperature, vert_dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:1012
+    r = _api.lfc_el(p, par, env, np.asarray(getattr(lcl_pressure, 'values', lcl_pressure)),
+                    np.asarray(getattr(lcl_temperature, 'values', lcl_temperature)))
+    return Dataset({k: _horiz(_np(r[k]), dims, coords, attrs=dict(_ATTRS[k]), name=k) for k in _LFC_KEYS})
+
+
+def cape_cin_base(pressure, temperature, lfc_pressure, el_pressure, parcel_temperature, vert_dim=VERT,
+                  pos_cape_neg_cin=True, post_zero_cin=False, **kwargs):
+    """pf.py:1291."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    env, _, _, _ = _split(temperature, vert_dim)
+    par, _, _, _ = _split(parcel_temperature, vert_dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:1221
+    r = _api.cape_cin_base(p, env, np.asarray(getattr(lfc_pressure, 'values', lfc_pressure)),
+                           np.asarray(getattr(el_pressure, 'values', el_pressure)), par,
+                           pos_cape_neg_cin=pos_cape_neg_cin, post_zero_cin=post_zero_cin)
+    res = Dataset({k: _horiz(_np(r[k]), dims, coords, attrs=dict(_ATTRS[k]), name=k) for k in ('cape', 'cin')})
+    res.attrs = []                                                                          # pf.py:1391
+    return res
+
+
+def most_unstable_parcel(dat, depth=300, vert_dim=VERT):
+    """pf.py:102: dat = Dataset with pressure, temperature, dewpoint."""
+    p, dims, coords, _ = _split(dat['pressure'], vert_dim)
+    t, _, _, _ = _split(dat['temperature'], vert_dim)
+    td, _, _, _ = _split(dat['dewpoint'], vert_dim)
+    r = _api.most_unstable_parcel(p, t, td, depth=depth)
+    return Dataset({k: _horiz(_np(r[k]), dims, coords, attrs=dict(getattr(dat[k], 'attrs', {})), name=k)
+                    for k in ('pressure', 'temperature', 'dewpoint')})
+
+
+def mixed_parcel(pressure, temperature, dewpoint, depth=100, vert_dim=VERT):
+    """pf.py:229."""
+    assert getattr(pressure, 'name', 'pressure') is not None, 'pressure requires name pressure.'   # pf.py:263
+    p, dims, coords, _ = _split(pressure, vert_dim)
+    t, _, _, _ = _split(temperature, vert_dim)
+    td, _, _, _ = _split(dewpoint, vert_dim)
+    r = _api.mixed_parcel(p, t, td, depth=depth)
+    mp = Dataset({k: _horiz(_np(r[k]), dims, coords, name=k) for k in ('pressure', 'temperature', 'dewpoint')})
+    mp.temperature.attrs.update({'long_name': 'Mixed parcel temperature', 'units': 'K'})
+    mp.dewpoint.attrs.update({'long_name': 'Mixed-parcel dewpoint'})
+    return mp
+
+
+def mixed_layer(dat, depth=100, vert_dim=VERT):
+    """pf.py:137: dat = Dataset with pressure and the variables to mix."""
+    p, dims, coords, _ = _split(dat['pressure'], vert_dim)
+    arrs = {'pressure': p}
+    for k in dat.keys():
+        if k != 'pressure':
+            arrs[k] = _split(dat[k], vert_dim)[0]
+    r = _api.mixed_layer(arrs, depth=depth)
+    return Dataset({k: _horiz(_np(v), dims, coords, name=k) for k, v in r.items()})
+
+
+# -- tables (pf.py:39-61) ------------------------------------------------------------------------------
+def load_moist_adiabat_lookups(**kwargs):
+    """pf.py:39: make the reference-format lookup tables available to moist='table' calls."""
+    from . import adiabat_tables
+    adiabat_tables.load_moist_adiabat_lookups(**kwargs)
+
+
+def lookup_tables_loaded():
+    """pf.py:56."""
+    from . import _lib
+    assert _lib.load().xp_tables_loaded(), 'Call load_moist_adiabat_lookups first.'
