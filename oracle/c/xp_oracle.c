@@ -160,20 +160,13 @@ static void moist_lapse_table(int n, const double *p, double t0, double pref, do
     const xpo_tables *T = &g_tables;
     for (int i = 0; i < n; i++) out[i] = NAN;
     if (!g_tables_loaded || isnan(t0) || isnan(pref)) return;
-    /* nearest neighbour on both coordinates; pandas get_indexer(method='nearest') resolves
-       ties towards the larger *index label position* ... see oracle/tables.py nearest_index */
+    /* nearest neighbour on both coordinates with pandas' tie rules (oracle/tables.py nearest_index_*): on the
+       DEcreasing pressure index the left (higher-pressure) label wins a tie, on the increasing temperature index
+       the right one */
     double fi = (T->p_max - pref) / T->p_step, fj = (t0 - T->t_min) / T->t_step;
-    int64_t i0 = (int64_t)floor(fi), j0 = (int64_t)floor(fj);
-    /* pressure coordinate is DEscending in the lookup (pf.py:53 keeps it unsorted) */
-    int64_t ip, jt;
-    {   /* candidates i0 (higher p) and i0+1 (lower p); distance in value space */
-        double d0 = fi - (double)i0, d1 = (double)(i0 + 1) - fi;
-        ip = (d1 < d0) ? i0 + 1 : i0;       /* tie -> i0?  resolved to match pandas in tables.py tests */
-        if (d0 == d1) ip = i0 + 1;
-        double e0 = fj - (double)j0, e1 = (double)(j0 + 1) - fj;
-        jt = (e1 < e0) ? j0 + 1 : j0;
-        if (e0 == e1) jt = j0 + 1;
-    }
+    double i0 = floor(fi), j0 = floor(fj);
+    int64_t ip = (int64_t)(((i0 + 1.0) - fi < fi - i0) ? i0 + 1.0 : i0);
+    int64_t jt = (int64_t)(((j0 + 1.0) - fj <= fj - j0) ? j0 + 1.0 : j0);
     if (ip < 0) ip = 0; if (ip > T->n_p - 1) ip = T->n_p - 1;
     if (jt < 0) jt = 0; if (jt > T->n_t - 1) jt = T->n_t - 1;
     uint16_t a = T->index[ip * T->n_t + jt];

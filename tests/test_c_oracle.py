@@ -42,3 +42,56 @@ def test_c_vs_python_oracle(parcel, mode):
             assert got['el_index'][c] == prof['el_index'], (c, got['el_index'][c], prof['el_index'])
     finally:
         po.set_moist_lapse('ode')
+
+
+# ---- reference lookup-table mode (pf.py:525-607) ------------------------------------------------------------
+@pytest.fixture(scope='module')
+def tables():
+    from oracle import tables as tb
+    tab = tb.get_tables()
+    co.set_tables(tab)
+    return tab
+
+
+@pytest.mark.parametrize('name', kr.MOIST_LAPSE_KATS)
+def test_table_mode_moist_lapse_kats(name, tables):
+    """run_moist_lapse_tests_looser (unit_tests.py:106-112): the four moist-lapse KATs at 2 decimals, through
+    the Python emulation and the C oracle."""
+    po.set_moist_lapse('table', tables)
+    try:
+        kr.run(name, po, loosen=2)
+    finally:
+        po.set_moist_lapse('ode')
+    co.set_moist_lapse('table')
+    try:
+        kr.run(name, co, loosen=2)
+    finally:
+        co.set_moist_lapse('rk4')
+
+
+def test_table_statistics_match_the_published_figures(tables):
+    """20 % of index cells are empty (plot at parcel_functions_demo.ipynb:221) and the table is within 0.037 K of
+    the ODE over 1000 -> 100 hPa, T0 = 250 ... 313 K (parcel_functions_demo.ipynb:252)."""
+    from oracle import tables as tb, thermo as th
+    assert abs((tables.index == 0).mean() - 0.202) < 0.005
+    worst = 0.0
+    p = np.arange(1000., 100., -4.)
+    for t0 in np.linspace(250, 313, 22):
+        a = tb.moist_lapse_table(tables, p, t0, 1000.)
+        b = th.moist_lapse_rk4(p, t0, 1000.)
+        worst = max(worst, float(np.nanmax(np.abs(a - b))))
+    assert 0.02 < worst < 0.0375, worst
+
+
+def test_table_mode_c_vs_python(tables):
+    p, t, td = synth.columns(nlev=40, ncol=40, seed=21, nan_fraction=0.1, dtype=np.float64)
+    got = co.cape_cin_grid(p, t, td, moist='table')
+    po.set_moist_lapse('table', tables)
+    try:
+        for c in range(p.shape[1]):
+            cc, prof = po.surface_based_cape_cin(p[:, c], t[:, c], td[:, c], per_column_lcl=True)
+            assert np.isclose(got['cape'][c], cc['cape'], rtol=1e-9, atol=1e-9), (c, got['cape'][c], cc['cape'])
+            assert np.isclose(got['cin'][c], cc['cin'], rtol=1e-9, atol=1e-9)
+            assert got['lfc_index'][c] == prof['lfc_index'] and got['el_index'][c] == prof['el_index']
+    finally:
+        po.set_moist_lapse('ode')

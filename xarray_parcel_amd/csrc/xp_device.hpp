@@ -32,37 +32,101 @@ constexpr double RK4_H_MAX = 0.1;     // exact-mode step bound in ln p (shared w
 XP_DEV double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 XP_DEV bool isnan_(double x) { return x != x; }
 
+// ---- fp64 math without the special-case handling of the device library -----------------------------
+// fp64 runs at half the fp32 VALU rate on CDNA4 and the library exp/log/pow/division carry ~2x the
+// instructions these need here (arguments are finite and far from overflow; NaN still propagates).
+XP_DEV double frcp(double x) {                       // ~1 ulp: v_rcp_f64 + two Newton steps
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+XP_DEV double fdiv(double a, double b) { return a * frcp(b); }
+XP_DEV double fexp(double x) {                       // |rel err| < 3e-16 for |x| < 700
+    double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878681e-09;                 // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.388888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+XP_DEV double flog(double x) {                       // fdlibm e_log.c kernel, positive finite x (NaN -> NaN)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);       // [0.5, 1)
+    bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    double f = m - 1.0;
+    double s = f * frcp(2.0 + f);
+    double z = s * s, w = z * z;
+    double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+XP_DEV double fpow(double x, double y) { return fexp(y * flog(x)); }
+
 // ---- thermodynamics ---------------------------------------------------------------------
-XP_DEV double sat_vapor_pressure(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
+// Bolton (1980): 6.112 fexp(17.67 (T-273.15)/(T-29.65)), written as fexp(17.67 - 17.67*243.5/(T-29.65))
+XP_DEV double sat_vapor_pressure(double t) { return 6.112 * fexp(__builtin_fma(-4302.645, frcp(t - 29.65), 17.67)); }
+// once per column (mixed-layer parcel): library log + IEEE division so that e = 0 -> -inf/inf -> NaN as in NumPy
 XP_DEV double dewpoint_of_e(double e) { double v = log(e / 6.112); return 273.15 + 243.5 * v / (17.67 - v); }
-XP_DEV double mix_of_e(double e, double p) { return EPS * e / (p - e); }
+XP_DEV double mix_of_e(double e, double p) { return EPS * fdiv(e, p - e); }
 XP_DEV double sat_mix(double p, double t) { return mix_of_e(sat_vapor_pressure(t), p); }
-XP_DEV double vapor_pressure(double p, double w) { return p * w / (EPS + w); }
-// pf.py:684-710: relative humidity (from dewpoint) times saturation mixing ratio
+XP_DEV double vapor_pressure(double p, double w) { return p * fdiv(w, EPS + w); }
+// pf.py:684-710: RH(T, Td) * w_s(p, T) = [e_s(Td)/e_s(T)] eps e_s(T)/(p - e_s(T)) = eps e_s(Td)/(p - e_s(T))
 XP_DEV double mixing_ratio(double t, double td, double p) {
-    double est = sat_vapor_pressure(t);
-    return (sat_vapor_pressure(td) / est) * mix_of_e(est, p);
+    return EPS * fdiv(sat_vapor_pressure(td), p - sat_vapor_pressure(t));
 }
 XP_DEV double virt(double t, double w) { return t * (1.0 + VT_EPS * w); }
 // Bolton (1980) eq. 39 (metpy.calc.equivalent_potential_temperature, pf.py:123)
 XP_DEV double theta_e(double p, double t, double td) {
     double e = sat_vapor_pressure(td), r = mix_of_e(e, p);
-    double tl = 56.0 + 1.0 / (1.0 / (td - 56.0) + log(t / td) / 800.0);
-    double thl = t / pow((p - e) / 1000.0, KAPPA) * pow(t / tl, 0.28 * r);
-    return thl * exp(r * (1.0 + 0.448 * r) * (3036.0 / tl - 1.78));
+    double tl = 56.0 + frcp(frcp(td - 56.0) + flog(fdiv(t, td)) * (1.0 / 800.0));
+    double thl = t * fpow(fdiv(1000.0, p - e), KAPPA) * fpow(fdiv(t, tl), 0.28 * r);
+    return thl * fexp(r * (1.0 + 0.448 * r) * (fdiv(3036.0, tl) - 1.78));
 }
 
 // ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
+// The LCL decides on which side of the condensation level every model level falls, and the reference's
+// parcel virtual temperature jumps there (its w_parcel = RH * w_s(T) differs from the w used by the LCL
+// iteration by ~1 %), so a level within rounding of the LCL is a knife edge (KAT test_profile_with_lcl_in_levels
+// puts a level exactly on it).  This once-per-column routine therefore keeps IEEE division and the device
+// library's exp/log/pow, written operation for operation like MetPy / the oracle, so that its result matches
+// theirs to the last bit wherever the libraries agree; the per-level code uses the fast forms above.
+XP_DEV double es_ref(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
+XP_DEV double dewpoint_ref(double e) { double v = log(e / 6.112); return 273.15 + 243.5 * v / (17.67 - v); }
 XP_DEV double lcl_iter(double p, double p0, double w, double t) {
-    double td = dewpoint_of_e(vapor_pressure(p, w));
+    double td = dewpoint_ref(p * w / (EPS + w));
     return p0 * pow(td / t, 1.0 / KAPPA);
+}
+// pf.py:684-710 + 782-804 in the reference's own operation order (RH * w_s, then Tv), library math
+XP_DEV double virt_ref(double t, double td, double p) {
+    double est = es_ref(t);
+    double w = (es_ref(td) / est) * (EPS * est / (p - est));
+    return t * (1.0 + VT_EPS * w);
 }
 struct Lcl { double p, t, tv; int not_converged; };
 XP_DEV Lcl lcl(double p_start, double t, double td) {
     Lcl r;
     r.not_converged = 0;
     if (isnan_(p_start) || isnan_(t) || isnan_(td)) { r.p = r.t = r.tv = qnan(); return r; }   // pf.py:627-634, 680
-    double w = mix_of_e(sat_vapor_pressure(td), p_start);
+    double es_td = es_ref(td);
+    double w = EPS * es_td / (p_start - es_td);
     double p0 = p_start, p = qnan();
     bool conv = false;
     for (int it = 0; it < 50; ++it) {
@@ -77,19 +141,20 @@ XP_DEV Lcl lcl(double p_start, double t, double td) {
     if (!conv) { p = qnan(); r.not_converged = 1; }
     if (fabs(p - p_start) <= 1e-8 + 1e-5 * fabs(p_start)) p = p_start;    // np.isclose snap (MetPy issue #1187)
     r.p = p;
-    r.t = dewpoint_of_e(vapor_pressure(p, w));
-    r.tv = virt(r.t, mix_of_e(sat_vapor_pressure(r.t), p));                // RH = 1 at the LCL (pf.py:653-657)
+    r.t = dewpoint_ref(p * w / (EPS + w));
+    r.tv = virt_ref(r.t, r.t, p);                                          // RH = 1 at the LCL (pf.py:653-657)
     return r;
 }
 
 // ---- moist adiabat ------------------------------------------------------------------------
 // dT/dln p of MetPy's pseudo-adiabat, one division (same grouping as the oracle)
-XP_DEV double dt_dlnp(double p, double t) {
-    double e = sat_vapor_pressure(t), pe = p - e;
-    double num = RD * t * pe + LV * EPS * e;
-    double den = CP_D * RD * t * t * pe + LV * LV * EPS * EPS * e;
-    return RD * t * t * num / den;
+XP_DEV double dt_dlnp_e(double p, double t, double e) {
+    double pe = p - e, rt2 = RD * t * t;
+    double num = __builtin_fma(RD * t, pe, (LV * EPS) * e);
+    double den = __builtin_fma(CP_D * rt2, pe, (LV * LV * EPS * EPS) * e);
+    return rt2 * fdiv(num, den);
 }
+XP_DEV double dt_dlnp(double p, double t) { return dt_dlnp_e(p, t, sat_vapor_pressure(t)); }
 
 struct Tables {               // reference-format lookup tables resident in HBM (pf.py:447-523)
     const uint16_t *index;    // [n_p][n_t], 0 = NaN
@@ -101,12 +166,13 @@ struct Tables {               // reference-format lookup tables resident in HBM 
 // Parcel temperature above the LCL.  Exact mode marches RK4 from node to node; table mode picks the
 // adiabat row once (nearest neighbour, pf.py:554-556) and interpolates linearly in p (pf.py:585-592).
 struct Moist {
-    double x, p, t;           // exact mode: current point on the adiabat (ln p, p, T)
+    double x, p, t, e;        // exact mode: current point on the adiabat (ln p, p, T) and e_s(T) there
     const float *row;         // table mode: selected adiabat, nullptr = NaN
     bool table, dead;
 
     XP_DEV void start(double p_ref, double x_ref, double t_ref, bool table_mode, const Tables &tb) {
         x = x_ref; p = p_ref; t = t_ref; table = table_mode; row = nullptr;
+        e = sat_vapor_pressure(t_ref);
         dead = isnan_(p_ref) || isnan_(t_ref);
         if (table_mode && !dead) {
             double fi = (tb.p_max - p_ref) / tb.p_step, fj = (t_ref - tb.t_min) / tb.t_step;
@@ -126,6 +192,7 @@ struct Moist {
     XP_DEV double at(double pk, double xk, const Tables &tb) {
         if (dead || isnan_(pk)) return qnan();
         if (table) {
+            // (table mode keeps IEEE division: it emulates np.interp on the reference's tables)
             double p_min = tb.p_max - (double)(tb.n_p - 1) * tb.p_step;
             if (row == nullptr || pk < p_min || pk > tb.p_max) return qnan();        // pf.py:598-600
             double f = (pk - p_min) / tb.p_step;
@@ -139,17 +206,18 @@ struct Moist {
             double dx = xk - x;
             int ns = (int)ceil(fabs(dx) / RK4_H_MAX - 1e-12);
             ns = ns < 1 ? 1 : ns;
-            double h = dx / (double)ns;
-            double rh = exp(0.5 * h);
+            double h = dx * frcp((double)ns);
+            double rh = fexp(0.5 * h);
             double ps = p;
             for (int s = 0; s < ns; ++s) {
                 double pm = ps * rh;
                 double pe = (s == ns - 1) ? pk : pm * rh;
-                double k1 = dt_dlnp(ps, t);
+                double k1 = dt_dlnp_e(ps, t, e);                 // e_s(T) at the current point is already known
                 double k2 = dt_dlnp(pm, t + 0.5 * h * k1);
                 double k3 = dt_dlnp(pm, t + 0.5 * h * k2);
                 double k4 = dt_dlnp(pe, t + h * k3);
-                t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+                t = t + (h * (1.0 / 6.0)) * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+                e = sat_vapor_pressure(t);
                 ps = pe;
             }
             x = xk; p = pk;
@@ -207,8 +275,8 @@ struct Scan {
                 double zy = frac * (y - yp) + yp;                               // zero crossing of y (pf.py:1225-1231)
                 if (!isnan_(zy)) {                                              // valid zero: two triangles (pf.py:1246-1273)
                     handled = true;
-                    double ps = exp(xs);
-                    double zlog = log(ps);                                      // pf.py:1237
+                    double ps = exp(xs);                                        // rare path: library exp/log, so that
+                    double zlog = log(ps);                                      // "p* < p_lcl" ties break as on the CPU (pf.py:1237)
                     add((yp * 0.5) * fabs(Xp - zlog));
                     double ys = frac * (par - parp) + parp;                     // pf.py:1050
                     if (!isnan_(ps)) {

@@ -91,8 +91,8 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
         if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - a.depth; }
         if (!isnan_(p) && p < top) {
             // insert the interpolated top row, close the integral; the profile continues from this level
-            double lt = log(top), cb = log(pb), ca = log(p);
-            double th_a = t / pow(p / 1000.0, KAPPA), w_a = sat_mix(p, td);
+            double lt = flog(top), cb = flog(pb), ca = flog(p);
+            double th_a = t / fpow(p / 1000.0, KAPPA), w_a = sat_mix(p, td);
             double cb2 = cb, ca2 = ca, tha = th_a, wa = w_a;
             if (pb == top) { ca2 = cb; tha = thb; wa = wb; }
             double th_t = interp_rule(thb, tha, lt, cb2, ca2), w_t = interp_rule(wb, wa, lt, cb2, ca2);
@@ -101,7 +101,7 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
             r.first = k; closed = true;
             break;
         }
-        double th = t / pow(p / 1000.0, KAPPA), w = sat_mix(p, td);
+        double th = t / fpow(p / 1000.0, KAPPA), w = sat_mix(p, td);
         if (k > 0) { layer_mean_step<T>(s_th, pp, thp, p, th); layer_mean_step<T>(s_w, pp, wp, p, w); }
         pp = p; thp = th; wp = w;
         if (!isnan_(p)) { pb = p; thb = th; wb = w; }
@@ -115,7 +115,7 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
     double depth = fabs(top - bottom);
     double th_m = (1.0 / depth) * s_th, w_m = (1.0 / depth) * s_w;
     r.p = p_start;                                                         // pf.py:250, 287
-    r.t = th_m * pow(p_start / 1000.0, KAPPA);                             // pf.py:268-269
+    r.t = th_m * fpow(p_start / 1000.0, KAPPA);                             // pf.py:268-269
     r.td = dewpoint_of_e(vapor_pressure(p_start, w_m));                    // pf.py:275-280
     return r;
 }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     int status = l.not_converged ? 2 : 0;
     const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
     double w_parcel = need_w ? mixing_ratio(pc.t, pc.td, pc.p) : 0.0;      // pf.py:748
-    const double x0 = log(pc.p), x_lcl = log(l.p);
+    const double x0 = flog(pc.p), x_lcl = log(l.p);
 
     Scan sc; sc.init(l.p, a.pos_neg != 0);
     Moist m; m.start(l.p, x_lcl, l.t, a.table_mode != 0, a.tb);
@@ -180,22 +180,24 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
         double te = interp_rule(tb_, ta2, at, cb, ca), tde = interp_rule(tdb, tda2, at, cb, ca);
-        double tve = need_w ? virt(te, mixing_ratio(te, tde, l.p)) : te;
+        // once per column, in the reference's operation order: for a saturated parcel (LCL == parcel level) the sign of
+        // parcel-minus-environment at this node is rounding noise of exactly these expressions
+        double tve = need_w ? virt_ref(te, tde, l.p) : te;
         emit(l.p, x_lcl, l.t, l.tv, te, tve, tde, true);
         lcl_done = true;
     };
     auto source = [&](double P, double T_, double Td_) {
-        double X = log(P);
+        double X = flog(P);
         if (isnan_(P) && !lcl_done && !lcl_nan) status |= 4;               // NaN pressure below the LCL (see xparcel.h)
         if (!lcl_done && !lcl_nan && P < l.p) emit_lcl(P, X, T_, Td_);
         double tp, w;
         if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
-            tp = pc.t * exp(KAPPA * (X - x0));
+            tp = pc.t * fexp(KAPPA * (X - x0));
             w = w_parcel;
-            if (need_w && P == l.p) w = mix_of_e(sat_vapor_pressure(m.at(P, X, a.tb)), P);   // pf.py:773 (<=)
+            if (need_w && P == l.p) { double ta = m.at(P, X, a.tb); w = mix_of_e(m.table ? sat_vapor_pressure(ta) : m.e, P); }   // pf.py:773 (<=)
         } else {
             tp = m.at(P, X, a.tb);                                         // NaN pressure -> NaN
-            w = need_w ? mix_of_e(sat_vapor_pressure(tp), P) : 0.0;        // pf.py:760
+            w = need_w ? mix_of_e(m.table ? sat_vapor_pressure(tp) : m.e, P) : 0.0;   // pf.py:760 (e_s(T) rides along with the RK4 state)
         }
         double tvp = need_w ? virt(tp, w) : tp;
         double tve = need_w ? virt(T_, mixing_ratio(T_, Td_, P)) : T_;     // pf.py:839-843
@@ -256,9 +258,9 @@ void k_mixed_layer(View pv, View vv, int64_t nlev, int64_t ncol, double depth_in
         double p = ld<T>(pv, k, c), v = ld<T>(vv, k, c);
         if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - depth_in; }
         if (!isnan_(p) && p < top) {
-            double cb = log(pb), ca = log(p), va = v;
+            double cb = flog(pb), ca = flog(p), va = v;
             if (pb == top) { ca = cb; va = vb; }
-            layer_mean_step<T>(s, pp, vp, top, interp_rule(vb, va, log(top), cb, ca));
+            layer_mean_step<T>(s, pp, vp, top, interp_rule(vb, va, flog(top), cb, ca));
             closed = true;
             break;
         }
@@ -290,7 +292,7 @@ void k_dry_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void
     else for (int64_t k = 0; k < nlev; ++k) { double p = ld<T>(pv, k, c); if (!isnan_(p) && !(p <= p0)) p0 = p; }
     for (int64_t k = 0; k < nlev; ++k) {
         double p = ld<T>(pv, k, c);
-        st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, t0 * pow(p / p0, KAPPA));
+        st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, t0 * fpow(p / p0, KAPPA));
     }
 }
 
@@ -305,17 +307,17 @@ void k_moist_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const vo
     const int f64 = sizeof(T) == 8;
     double t0 = ld1<T>(pt, c);
     double p0 = pp ? ld1<T>(pp, c) : ld<T>(pv, 0, c);                      // pf.py:549-550
-    double x0 = log(p0);
+    double x0 = flog(p0);
     Moist m; m.start(p0, x0, t0, table_mode != 0, tb);
     for (int64_t k = 0; k < nlev; ++k) {
         double p = ld<T>(pv, k, c);
-        if (p <= p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, log(p), tb));
+        if (p <= p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, flog(p), tb));
         else if (isnan_(p)) st(out.data, f64, k * out.ls + c * out.cs, qnan());
     }
     m.start(p0, x0, t0, table_mode != 0, tb);
     for (int64_t k = nlev - 1; k >= 0; --k) {
         double p = ld<T>(pv, k, c);
-        if (p > p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, log(p), tb));
+        if (p > p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, flog(p), tb));
     }
 }
 
@@ -329,16 +331,16 @@ void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const
     double p0 = ld1<T>(pp, c), t0 = ld1<T>(pt, c), td0 = ld1<T>(ptd, c);
     Lcl l = lcl(p0, t0, td0);
     double w_parcel = mixing_ratio(t0, td0, p0);
-    double x_lcl = log(l.p);
+    double x_lcl = flog(l.p);
     Moist m; m.start(l.p, x_lcl, l.t, table_mode != 0, tb);
     for (int64_t k = 0; k < nlev; ++k) {
         double P = ld<T>(pv, k, c);
         double tp, w;
         if (P >= l.p) {
-            tp = t0 * pow(P / p0, KAPPA);
+            tp = t0 * fpow(P / p0, KAPPA);
             w = (P == l.p) ? mix_of_e(sat_vapor_pressure(l.t), P) : w_parcel;
         } else {
-            tp = m.at(P, log(P), tb);
+            tp = m.at(P, flog(P), tb);
             w = mix_of_e(sat_vapor_pressure(tp), P);
         }
         if (ot.data) st(ot.data, f64, k * ot.ls + c * ot.cs, tp);
@@ -357,7 +359,7 @@ void k_lfc_el(View pv, View parv, View envv, int64_t nlev, int64_t ncol, const v
     Scan sc; sc.init(lp, true);
     for (int64_t k = 0; k < nlev; ++k) {
         double P = ld<T>(pv, k, c);
-        sc.node(P, log(P), ld<T>(parv, k, c), ld<T>(envv, k, c), false);
+        sc.node(P, flog(P), ld<T>(parv, k, c), ld<T>(envv, k, c), false);
     }
     Scan::Result r = sc.finish(lt, false);
     st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t); st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
@@ -378,7 +380,7 @@ void k_cape_cin_base(View pv, View envv, View parv, int64_t nlev, int64_t ncol, 
     }
     double sc_ = 0.0, sn = 0.0, Pp = qnan(), Xp = qnan(), yp = qnan();
     for (int64_t k = 0; k < nlev; ++k) {
-        double P = ld<T>(pv, k, c), X = log(P), y = ld<T>(parv, k, c) - ld<T>(envv, k, c);
+        double P = ld<T>(pv, k, c), X = flog(P), y = ld<T>(parv, k, c) - ld<T>(envv, k, c);
         if (k > 0) {
             bool ynan = isnan_(y) || isnan_(yp);
             double s0 = (double)((yp > 0.0) - (yp < 0.0)), s1 = (double)((y > 0.0) - (y < 0.0));
@@ -388,11 +390,11 @@ void k_cape_cin_base(View pv, View envv, View parv, int64_t nlev, int64_t ncol, 
                 double zy = ((xs - Xp) / (X - Xp)) * (y - yp) + yp;
                 if (!isnan_(zy)) {
                     handled = true;
-                    double zlog = log(exp(xs));
-                    double dx = Xp - zlog, a0 = (yp * 0.5) * fabs(dx), pm = exp(Xp - dx * 0.5);
+                    double zlog = flog(fexp(xs));
+                    double dx = Xp - zlog, a0 = (yp * 0.5) * fabs(dx), pm = fexp(Xp - dx * 0.5);
                     if (pm <= L && pm >= E && (!pos_neg || a0 > 0.0)) sc_ += a0;
                     if (pm >= L && (!pos_neg || a0 < 0.0)) sn += a0;
-                    dx = X - zlog; a0 = (y * 0.5) * fabs(dx); pm = exp(X - dx * 0.5);
+                    dx = X - zlog; a0 = (y * 0.5) * fabs(dx); pm = fexp(X - dx * 0.5);
                     if (pm <= L && pm >= E && (!pos_neg || a0 > 0.0)) sc_ += a0;
                     if (pm >= L && (!pos_neg || a0 < 0.0)) sn += a0;
                 }
