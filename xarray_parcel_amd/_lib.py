@@ -6,7 +6,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libxparcel.so')
+LIB_PATH = os.environ.get('XPARCEL_LIB') or os.path.join(_HERE, 'lib', 'libxparcel.so')   # env override: A/B builds
 SRC_DIR = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include', 'xparcel.h')
 

@@ -101,6 +101,57 @@ XP_DEV double theta_e(double p, double t, double td) {
     return thl * fexp(r * (1.0 + 0.448 * r) * (fdiv(3036.0, tl) - 1.78));
 }
 
+// out-of-line copies of the slow paths: called from rare, ballot-guarded branches so that their polynomial
+// constants and temporaries do not occupy registers of the per-level loop
+__device__ __attribute__((noinline)) double sat_vapor_pressure_slow(double t) { return sat_vapor_pressure(t); }
+__device__ __attribute__((noinline)) double exp_slow(double x) { return exp(x); }
+__device__ __attribute__((noinline)) double log_slow(double x) { return log(x); }
+
+// ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
+// The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
+// exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a 10 KB table into LDS:
+// 160 one-kelvin intervals over 170..330 K, a degree-7 polynomial in r = T - centre each (Chebyshev
+// interpolant of Bolton's formula built in long double by xp_init; relative error < 3e-15), stored
+// coefficient-major so that the lanes of a wavefront -- whose temperatures fall in different intervals --
+// hit different LDS banks.  Out-of-range or NaN temperatures take the formula.
+constexpr double ES_T_LO = 170.0;
+constexpr int ES_N = 160, ES_DEG = 7, ES_TAB = (ES_DEG + 1) * ES_N;
+XP_DEV double es_tab(const double *tb, double t) {
+    double u = t - ES_T_LO;
+    bool ok = (u >= 0.0) && (u < (double)ES_N);
+    int i = (int)u;                                  // NaN -> 0
+    i = i < 0 ? 0 : (i > ES_N - 1 ? ES_N - 1 : i);
+    double r = u - ((double)i + 0.5);
+    const double *c = tb + i;
+    double p = c[7 * ES_N];
+    p = __builtin_fma(p, r, c[6 * ES_N]);
+    p = __builtin_fma(p, r, c[5 * ES_N]);
+    p = __builtin_fma(p, r, c[4 * ES_N]);
+    p = __builtin_fma(p, r, c[3 * ES_N]);
+    p = __builtin_fma(p, r, c[2 * ES_N]);
+    p = __builtin_fma(p, r, c[1 * ES_N]);
+    p = __builtin_fma(p, r, c[0]);
+    // out-of-table (or NaN) temperatures: the formula, behind a wave-uniform test so that the compiler cannot
+    // fold the slow path into the fast one as a select
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+        if (!ok) {
+            double tt = t;
+            asm volatile("" : "+v"(tt));             // pins the slow path inside this branch (no speculation)
+            p = sat_vapor_pressure_slow(tt);
+        }
+    }
+    return p;
+}
+XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p) {
+    return EPS * fdiv(es_tab(tb, td), p - es_tab(tb, t));
+}
+// stage the table (global -> LDS); every thread of the block must call this before any early return
+XP_DEV const double *stage_es_table(const double *g, double *lds) {
+    for (int i = threadIdx.x; i < ES_TAB; i += blockDim.x) lds[i] = g[i];
+    __syncthreads();
+    return lds;
+}
+
 // ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
 // The LCL decides on which side of the condensation level every model level falls, and the reference's
 // parcel virtual temperature jumps there (its w_parcel = RH * w_s(T) differs from the w used by the LCL
@@ -154,7 +205,7 @@ XP_DEV double dt_dlnp_e(double p, double t, double e) {
     double den = __builtin_fma(CP_D * rt2, pe, (LV * LV * EPS * EPS) * e);
     return rt2 * fdiv(num, den);
 }
-XP_DEV double dt_dlnp(double p, double t) { return dt_dlnp_e(p, t, sat_vapor_pressure(t)); }
+XP_DEV double dt_dlnp(const double *es, double p, double t) { return dt_dlnp_e(p, t, es_tab(es, t)); }
 
 struct Tables {               // reference-format lookup tables resident in HBM (pf.py:447-523)
     const uint16_t *index;    // [n_p][n_t], 0 = NaN
@@ -168,11 +219,12 @@ struct Tables {               // reference-format lookup tables resident in HBM 
 struct Moist {
     double x, p, t, e;        // exact mode: current point on the adiabat (ln p, p, T) and e_s(T) there
     const float *row;         // table mode: selected adiabat, nullptr = NaN
+    const double *es;         // LDS e_s table
     bool table, dead;
 
-    XP_DEV void start(double p_ref, double x_ref, double t_ref, bool table_mode, const Tables &tb) {
-        x = x_ref; p = p_ref; t = t_ref; table = table_mode; row = nullptr;
-        e = sat_vapor_pressure(t_ref);
+    XP_DEV void start(const double *es_lds, double p_ref, double x_ref, double t_ref, bool table_mode, const Tables &tb) {
+        es = es_lds; x = x_ref; p = p_ref; t = t_ref; table = table_mode; row = nullptr;
+        e = es_tab(es, t_ref);
         dead = isnan_(p_ref) || isnan_(t_ref);
         if (table_mode && !dead) {
             double fi = (tb.p_max - p_ref) / tb.p_step, fj = (t_ref - tb.t_min) / tb.t_step;
@@ -204,20 +256,29 @@ struct Moist {
         }
         if (xk != x) {
             double dx = xk - x;
-            int ns = (int)ceil(fabs(dx) / RK4_H_MAX - 1e-12);
+            int ns = (int)ceil(fabs(dx) * (1.0 / RK4_H_MAX) - 1e-12);
             ns = ns < 1 ? 1 : ns;
             double h = dx * frcp((double)ns);
-            double rh = fexp(0.5 * h);
+            double q = 0.5 * h;                                   // |q| <= 0.05: exp(q) by its Taylor series to q^8 (< 1e-17)
+            double rh = 2.48015873015873e-05;
+            rh = __builtin_fma(rh, q, 1.984126984126984e-04);
+            rh = __builtin_fma(rh, q, 1.388888888888889e-03);
+            rh = __builtin_fma(rh, q, 8.333333333333333e-03);
+            rh = __builtin_fma(rh, q, 4.1666666666666664e-02);
+            rh = __builtin_fma(rh, q, 1.6666666666666666e-01);
+            rh = __builtin_fma(rh, q, 0.5);
+            rh = __builtin_fma(rh, q, 1.0);
+            rh = __builtin_fma(rh, q, 1.0);
             double ps = p;
             for (int s = 0; s < ns; ++s) {
                 double pm = ps * rh;
                 double pe = (s == ns - 1) ? pk : pm * rh;
                 double k1 = dt_dlnp_e(ps, t, e);                 // e_s(T) at the current point is already known
-                double k2 = dt_dlnp(pm, t + 0.5 * h * k1);
-                double k3 = dt_dlnp(pm, t + 0.5 * h * k2);
-                double k4 = dt_dlnp(pe, t + h * k3);
+                double k2 = dt_dlnp(es, pm, t + 0.5 * h * k1);
+                double k3 = dt_dlnp(es, pm, t + 0.5 * h * k2);
+                double k4 = dt_dlnp(es, pe, t + h * k3);
                 t = t + (h * (1.0 / 6.0)) * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
-                e = sat_vapor_pressure(t);
+                e = es_tab(es, t);
                 ps = pe;
             }
             x = xk; p = pk;
@@ -253,10 +314,9 @@ struct Scan {
         any_inc = pos_parcel = env_any = false;
         top_p = top_par = top_env = min_p = qnan();
     }
-    XP_DEV void add(double a) {
-        if (isnan_(a)) return;                       // skip-NaN sums (pf.py:206)
-        if (!pos_neg || a > 0.0) cape += a;
-        if (!pos_neg || a < 0.0) cin += a;
+    XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
+        if (pos_neg) { cape += fmax(a, 0.0); cin += fmin(a, 0.0); }      // maxNum/minNum drop a NaN operand
+        else { double b = isnan_(a) ? 0.0 : a; cape += b; cin += b; }
     }
     XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
         double y = par - env;
@@ -264,19 +324,18 @@ struct Scan {
             use_all = (env != par);
         } else {
             int i = j - 1;
-            // sign(a-b).diff() != 0, NaN counts as flagged (pf.py:1019-1022)
-            bool ynan = isnan_(y) || isnan_(yp);
-            double s0 = (double)((yp > 0.0) - (yp < 0.0)), s1 = (double)((y > 0.0) - (y < 0.0));
-            bool flagged = ynan || (s1 != s0);
+            // sign(a-b).diff() != 0, NaN counts as flagged (pf.py:1019-1022): same sign <=> y*yp > 0 or both zero
+            bool flagged = !((y * yp > 0.0) || (y == 0.0 && yp == 0.0));
             bool handled = false;
-            if (flagged) {
+            // rare: ballot first, so the crossing arithmetic is not speculated into the per-level path
+            if (__builtin_amdgcn_ballot_w64(flagged) != 0ull && flagged) {
                 double xs = (y * Xp - yp * X) / (y - yp);                       // pf.py:1046
                 double frac = (xs - Xp) / (X - Xp);
                 double zy = frac * (y - yp) + yp;                               // zero crossing of y (pf.py:1225-1231)
                 if (!isnan_(zy)) {                                              // valid zero: two triangles (pf.py:1246-1273)
                     handled = true;
-                    double ps = exp(xs);                                        // rare path: library exp/log, so that
-                    double zlog = log(ps);                                      // "p* < p_lcl" ties break as on the CPU (pf.py:1237)
+                    double ps = exp_slow(xs);                                   // rare path: library exp/log, so that
+                    double zlog = log_slow(ps);                                      // "p* < p_lcl" ties break as on the CPU (pf.py:1237)
                     add((yp * 0.5) * fabs(Xp - zlog));
                     double ys = frac * (par - parp) + parp;                     // pf.py:1050
                     if (!isnan_(ps)) {

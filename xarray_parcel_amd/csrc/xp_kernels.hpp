@@ -38,6 +38,7 @@ struct CapeArgs {
     double depth;
     int vtc, log_interp, pos_neg, post_zero, table_mode;
     Tables tb;
+    const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
     ScalarsOut s;
     ProfileOut prof;
 };
@@ -123,8 +124,15 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // ---------------------------------------------------------------------------------------------
 // cape_cin (pf.py:1394-1475) and its drivers, fused: parcel selection, LCL, parcel profile with
 // the LCL as a virtual level, LFC/EL, CAPE/CIN, optional profile output.
-template <typename T, int PMODE, bool PROFILE>
+//
+// The level loop runs in two wave-uniform phases.  Phase A (some lane of the wavefront is still at or below
+// its LCL; decided with a ballot) carries the full logic: dry or moist parcel, bracketing levels for the
+// environment at the LCL, emission of the LCL node.  Phase B (every lane above its LCL) is the steady state
+// and only advances the moist adiabat, so the LCL machinery costs nothing for most of the column.
+template <typename T, int PMODE, bool PROFILE, bool TABLE>
 __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
+    __shared__ double s_es[ES_TAB];
+    const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
 
@@ -142,17 +150,32 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     }
 
     const bool need_w = a.vtc || PROFILE;
-    Lcl l = lcl(pc.p, pc.t, pc.td);
+    const Lcl l = lcl(pc.p, pc.t, pc.td);
     int status = l.not_converged ? 2 : 0;
+    const ScalarsOut &s = a.s;
+
+    if (isnan_(l.p)) {
+        // NaN parcel / LCL blanks the whole profile (pf.py:965-985): CAPE = CIN = 0.0, everything else NaN
+        if (PROFILE)
+            for (int64_t j = 0; j < a.prof.nlev_out; ++j)
+                for (int v = 0; v < 6; ++v) st(a.prof.v[v], a.prof.f64, j * a.prof.ls + c * a.prof.cs, qnan());
+        st(s.cape, s.f64, c, 0.0); st(s.cin, s.f64, c, 0.0);
+        st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
+        st(s.lfc_p, s.f64, c, qnan()); st(s.lfc_t, s.f64, c, qnan()); st(s.el_p, s.f64, c, qnan()); st(s.el_t, s.f64, c, qnan());
+        sti(s.lfc_idx, c, -1); sti(s.el_idx, c, -1); sti(s.status, c, status); sti(s.parcel_idx, c, pc.idx);
+        st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
+        return;
+    }
+
     const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
-    double w_parcel = need_w ? mixing_ratio(pc.t, pc.td, pc.p) : 0.0;      // pf.py:748
+    const double w_parcel = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0; // pf.py:748
     const double x0 = flog(pc.p), x_lcl = log(l.p);
 
     Scan sc; sc.init(l.p, a.pos_neg != 0);
-    Moist m; m.start(l.p, x_lcl, l.t, a.table_mode != 0, a.tb);
+    Moist m; m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int64_t jout = 0;                                                      // profile row
-    auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) {
+    auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
             if (jout < a.prof.nlev_out) {
                 int64_t o = jout * a.prof.ls + c * a.prof.cs;
@@ -169,10 +192,9 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         sc.node(P, X, a.vtc ? tvp : tp, a.vtc ? tve : te, is_lcl);
     };
 
-    const bool lcl_nan = isnan_(l.p);
     bool lcl_done = false;
     double pb = qnan(), xb = qnan(), tb_ = qnan(), tdb = qnan();          // last valid-pressure node at or below the LCL
-    auto emit_lcl = [&](double pa, double xa, double ta, double tda) {
+    auto emit_lcl = [&](double pa, double xa, double ta, double tda) __attribute__((always_inline)) {
         // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811),
         // then virtual temperature recomputed from the interpolated T, Td (pf.py:911-920)
         double at = a.log_interp ? x_lcl : l.p;
@@ -180,28 +202,42 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
         double te = interp_rule(tb_, ta2, at, cb, ca), tde = interp_rule(tdb, tda2, at, cb, ca);
-        // once per column, in the reference's operation order: for a saturated parcel (LCL == parcel level) the sign of
-        // parcel-minus-environment at this node is rounding noise of exactly these expressions
-        double tve = need_w ? virt_ref(te, tde, l.p) : te;
+        // for a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at this node is rounding
+        // noise of exactly the reference's expressions: those columns evaluate them in its operation order
+        double tve = te;
+        if (need_w) {
+            bool tie = (l.p == pc.p);                                      // saturated parcel: LCL snapped onto the parcel level
+            tve = virt(te, mixing_ratio_tab(es, te, tde, l.p));
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = te; asm volatile("" : "+v"(q)); tve = virt_ref(q, tde, l.p); }
+        }
         emit(l.p, x_lcl, l.t, l.tv, te, tve, tde, true);
         lcl_done = true;
     };
-    auto source = [&](double P, double T_, double Td_) {
+    // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
+    auto moist_node = [&](double P, double X, double T_, double Td_) __attribute__((always_inline)) {
+        double tp = m.at(P, X, a.tb);                                      // NaN pressure -> NaN
+        double w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;                  // pf.py:760
+        double tvp = need_w ? virt(tp, w) : tp;
+        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
+        emit(P, X, tp, tvp, T_, tve, Td_, false);
+    };
+    auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
         double X = flog(P);
-        if (isnan_(P) && !lcl_done && !lcl_nan) status |= 4;               // NaN pressure below the LCL (see xparcel.h)
-        if (!lcl_done && !lcl_nan && P < l.p) emit_lcl(P, X, T_, Td_);
+        if (isnan_(P) && !lcl_done) status |= 4;                           // NaN pressure below the LCL (see xparcel.h)
+        if (!lcl_done && P < l.p) emit_lcl(P, X, T_, Td_);
+        // lanes of one wavefront sit on both sides of their LCLs here: only the parcel temperature / mixing ratio
+        // is branched, the environment and the scan node are shared
         double tp, w;
         if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
             tp = pc.t * fexp(KAPPA * (X - x0));
             w = w_parcel;
-            if (need_w && P == l.p) { double ta = m.at(P, X, a.tb); w = mix_of_e(m.table ? sat_vapor_pressure(ta) : m.e, P); }   // pf.py:773 (<=)
+            if (need_w && P == l.p) { double ta = m.at(P, X, a.tb); w = mix_of_e(TABLE ? es_tab(es, ta) : m.e, P); }   // pf.py:773 (<=)
         } else {
-            tp = m.at(P, X, a.tb);                                         // NaN pressure -> NaN
-            w = need_w ? mix_of_e(m.table ? sat_vapor_pressure(tp) : m.e, P) : 0.0;   // pf.py:760 (e_s(T) rides along with the RK4 state)
+            tp = m.at(P, X, a.tb);
+            w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;
         }
         double tvp = need_w ? virt(tp, w) : tp;
-        double tve = need_w ? virt(T_, mixing_ratio(T_, Td_, P)) : T_;     // pf.py:839-843
-        if (lcl_nan) { P = X = tp = tvp = T_ = tve = Td_ = qnan(); }       // NaN LCL blanks the whole profile (pf.py:965-985)
+        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
         emit(P, X, tp, tvp, T_, tve, Td_, false);
         if (!isnan_(P) && !lcl_done) { pb = P; xb = X; tb_ = T_; tdb = Td_; }
     };
@@ -211,15 +247,18 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     int64_t k = pc.first;
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
-    for (; k < a.nlev; ++k) {
+    for (; k < a.nlev; ++k) {                                              // phase A
+        if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
         double P = np_, T_ = nt_, Td_ = ntd_;
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         source(P, T_, Td_);
     }
-    if (!lcl_done) {
-        if (lcl_nan) emit(qnan(), qnan(), qnan(), qnan(), qnan(), qnan(), qnan(), true);
-        else emit_lcl(qnan(), qnan(), qnan(), qnan());                     // LCL above the top level: no upper bracket
+    for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
+        double P = np_, T_ = nt_, Td_ = ntd_;
+        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        moist_node(P, flog(P), T_, Td_);
     }
+    if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (PROFILE) {
         for (; jout < a.prof.nlev_out; ++jout) {
             int64_t o = jout * a.prof.ls + c * a.prof.cs;
@@ -229,7 +268,6 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
 
     Scan::Result r = sc.finish(lcl_t_arg, a.post_zero != 0);
     status |= r.status;
-    const ScalarsOut &s = a.s;
     st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
     st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
     st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t);
@@ -301,20 +339,22 @@ void k_dry_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void
 // (pressure must decrease with level index on each side, the reference's input contract).
 template <typename T> __global__ __launch_bounds__(256)
 void k_moist_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void *pp, int table_mode, Tables tb,
-                   OutView out) {
+                   const double *es_g, OutView out) {
+    __shared__ double s_es[ES_TAB];
+    const double *es = stage_es_table(es_g, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     const int f64 = sizeof(T) == 8;
     double t0 = ld1<T>(pt, c);
     double p0 = pp ? ld1<T>(pp, c) : ld<T>(pv, 0, c);                      // pf.py:549-550
     double x0 = flog(p0);
-    Moist m; m.start(p0, x0, t0, table_mode != 0, tb);
+    Moist m; m.start(es, p0, x0, t0, table_mode != 0, tb);
     for (int64_t k = 0; k < nlev; ++k) {
         double p = ld<T>(pv, k, c);
         if (p <= p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, flog(p), tb));
         else if (isnan_(p)) st(out.data, f64, k * out.ls + c * out.cs, qnan());
     }
-    m.start(p0, x0, t0, table_mode != 0, tb);
+    m.start(es, p0, x0, t0, table_mode != 0, tb);
     for (int64_t k = nlev - 1; k >= 0; --k) {
         double p = ld<T>(pv, k, c);
         if (p > p0) st(out.data, f64, k * out.ls + c * out.cs, m.at(p, flog(p), tb));
@@ -324,7 +364,10 @@ void k_moist_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const vo
 // parcel_profile (pf.py:712-780) without the LCL level
 template <typename T> __global__ __launch_bounds__(256)
 void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const void *pt, const void *ptd,
-                      int table_mode, Tables tb, OutView ot, OutView otv, void *olp, void *olt, void *oltv) {
+                      int table_mode, Tables tb, const double *es_g, OutView ot, OutView otv, void *olp, void *olt,
+                      void *oltv) {
+    __shared__ double s_es[ES_TAB];
+    const double *es = stage_es_table(es_g, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     const int f64 = sizeof(T) == 8;
@@ -332,7 +375,7 @@ void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const
     Lcl l = lcl(p0, t0, td0);
     double w_parcel = mixing_ratio(t0, td0, p0);
     double x_lcl = flog(l.p);
-    Moist m; m.start(l.p, x_lcl, l.t, table_mode != 0, tb);
+    Moist m; m.start(es, l.p, x_lcl, l.t, table_mode != 0, tb);
     for (int64_t k = 0; k < nlev; ++k) {
         double P = ld<T>(pv, k, c);
         double tp, w;

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -34,9 +35,40 @@ struct State {
     bool tables = false;
     xp::Tables tb{};
     void *tb_index = nullptr, *tb_adiabats = nullptr;
+    double *es_tab = nullptr;   // device copy of the e_s(T) polynomial table
 } g;
 
 size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
+
+// e_s(T) table for xp::es_tab: per 1 K interval the degree-7 interpolant of Bolton's formula at Chebyshev nodes,
+// monomial coefficients in r = T - centre, built in long double; layout [coefficient][interval].
+void build_es_table(double *out) {
+    using LD = long double;
+    const int n = xp::ES_DEG + 1;
+    const LD pi = 3.14159265358979323846264338327950288L;
+    for (int i = 0; i < xp::ES_N; ++i) {
+        LD centre = (LD)xp::ES_T_LO + (LD)i + 0.5L;
+        LD A[8][9];
+        for (int k = 0; k < n; ++k) {
+            LD r = 0.5L * cosl(pi * ((LD)k + 0.5L) / (LD)n);
+            LD t = centre + r;
+            LD v = 1.0L;
+            for (int j = 0; j < n; ++j) { A[k][j] = v; v *= r; }
+            A[k][n] = 6.112L * expl(17.67L * (t - 273.15L) / (t - 29.65L));
+        }
+        for (int col = 0; col < n; ++col) {                     // Gaussian elimination with partial pivoting
+            int piv = col;
+            for (int r = col + 1; r < n; ++r) if (fabsl(A[r][col]) > fabsl(A[piv][col])) piv = r;
+            for (int j = 0; j <= n; ++j) { LD t_ = A[col][j]; A[col][j] = A[piv][j]; A[piv][j] = t_; }
+            for (int r = 0; r < n; ++r) {
+                if (r == col) continue;
+                LD f = A[r][col] / A[col][col];
+                for (int j = col; j <= n; ++j) A[r][j] -= f * A[col][j];
+            }
+        }
+        for (int j = 0; j < n; ++j) out[j * xp::ES_N + i] = (double)(A[j][n] / A[j][j]);
+    }
+}
 
 // Stages host buffers through device scratch for one call; device buffers pass through.
 struct Stager {
@@ -123,10 +155,14 @@ int stage_scalars(Stager &st, xp_scalars_out *s, int64_t ncol, xp::ScalarsOut *o
     return rc;
 }
 
+template <typename T, int PM, bool TABLE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
+    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, TABLE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, TABLE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+}
 template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     if (a.ncol == 0) return;
-    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+    if (a.table_mode) launch_cape_t<T, PM, true>(a, profile, s);
+    else launch_cape_t<T, PM, false>(a, profile, s);
 }
 template <typename T> void launch_cape_pm(const xp::CapeArgs &a, int pm, bool profile, hipStream_t s) {
     switch (pm) {
@@ -148,6 +184,7 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     if ((rc = stage_view(st, p, &a->p)) || (rc = stage_view(st, t, &a->t)) || (rc = stage_view(st, td, &a->td))) return rc;
     a->nlev = p->nlev; a->ncol = p->ncol;
     a->depth = parcel->depth;
+    a->es_tab = g.es_tab;
     if (parcel->mode == XP_PARCEL_EXPLICIT) {
         if (!parcel->pressure || !parcel->temperature || !parcel->dewpoint) return fail(XP_E_ARG, "explicit parcel: null arrays");
         size_t b = (size_t)p->ncol * esize(p->dtype);
@@ -188,6 +225,13 @@ int xp_init(int device) {
         // tables live on the old device; drop them, the caller reloads
         (void)hipFree(g.tb_index); (void)hipFree(g.tb_adiabats);
         g.tb_index = g.tb_adiabats = nullptr; g.tables = false;
+    }
+    if (g.init && g.device != device && g.es_tab) { (void)hipFree(g.es_tab); g.es_tab = nullptr; }
+    if (!g.es_tab) {
+        std::vector<double> tab(xp::ES_TAB);
+        build_es_table(tab.data());
+        HIP_TRY(hipMalloc((void **)&g.es_tab, sizeof(double) * xp::ES_TAB));
+        HIP_TRY(hipMemcpy(g.es_tab, tab.data(), sizeof(double) * xp::ES_TAB, hipMemcpyHostToDevice));
     }
     g.device = device;
     g.init = true;
@@ -338,8 +382,8 @@ int xp_moist_lapse(const xp_view *p, const void *pt, const void *pp, int32_t moi
     xp::Tables tb = g.tb;
     int tm = moist_mode == XP_MOIST_TABLE;
     if (p->ncol) {
-        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_moist_lapse<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, ov);
-        else hipLaunchKernelGGL((xp::k_moist_lapse<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, ov);
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_moist_lapse<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, (const double *)g.es_tab, ov);
+        else hipLaunchKernelGGL((xp::k_moist_lapse<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, (const double *)g.es_tab, ov);
     }
     return st.finish();
 }
@@ -364,8 +408,8 @@ int xp_parcel_profile(const xp_view *p, const void *pp, const void *pt, const vo
     xp::Tables tb = g.tb;
     int tm = moist_mode == XP_MOIST_TABLE;
     if (p->ncol) {
-        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_parcel_profile<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, ot, otv, d3, d4, d5);
-        else hipLaunchKernelGGL((xp::k_parcel_profile<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, ot, otv, d3, d4, d5);
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_parcel_profile<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, (const double *)g.es_tab, ot, otv, d3, d4, d5);
+        else hipLaunchKernelGGL((xp::k_parcel_profile<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, (const double *)g.es_tab, ot, otv, d3, d4, d5);
     }
     return st.finish();
 }
