@@ -114,13 +114,21 @@ __device__ __attribute__((noinline)) double log_slow(double x) { return log(x); 
 // interpolant of Bolton's formula built in long double by xp_init; relative error < 3e-15), stored
 // coefficient-major so that the lanes of a wavefront -- whose temperatures fall in different intervals --
 // hit different LDS banks.  Out-of-range or NaN temperatures take the formula.
-constexpr double ES_T_LO = 170.0;
-constexpr int ES_N = 160, ES_DEG = 7, ES_TAB = (ES_DEG + 1) * ES_N;
-XP_DEV double es_tab(const double *tb, double t) {
+constexpr double ES_T_LO = 120.0;
+constexpr int ES_N = 210, ES_DEG = 7, ES_TAB = (ES_DEG + 1) * ES_N;
+constexpr int LOG_N = 64, LOG_TAB = 2 * LOG_N;      // ln table: 1/c_i and ln c_i for 64 mantissa intervals
+constexpr int LDS_TAB = ES_TAB + LOG_TAB;
+// `all_in_range` is a wave-uniform promise by the caller that every lane's t lies inside the table (the per-level
+// code tests T, Td and the parcel temperature once per level with margins, see in_table()); without it the
+// range test is made here and out-of-table / NaN lanes take the formula.
+XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     double u = t - ES_T_LO;
-    bool ok = (u >= 0.0) && (u < (double)ES_N);
     int i = (int)u;                                  // NaN -> 0
-    i = i < 0 ? 0 : (i > ES_N - 1 ? ES_N - 1 : i);
+    bool ok = true;
+    if (!all_in_range) {
+        ok = (u >= 0.0) && (u < (double)ES_N);
+        i = i < 0 ? 0 : (i > ES_N - 1 ? ES_N - 1 : i);
+    }
     double r = u - ((double)i + 0.5);
     const double *c = tb + i;
     double p = c[7 * ES_N];
@@ -131,23 +139,44 @@ XP_DEV double es_tab(const double *tb, double t) {
     p = __builtin_fma(p, r, c[2 * ES_N]);
     p = __builtin_fma(p, r, c[1 * ES_N]);
     p = __builtin_fma(p, r, c[0]);
-    // out-of-table (or NaN) temperatures: the formula, behind a wave-uniform test so that the compiler cannot
-    // fold the slow path into the fast one as a select
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
-        if (!ok) {
-            double tt = t;
-            asm volatile("" : "+v"(tt));             // pins the slow path inside this branch (no speculation)
-            p = sat_vapor_pressure_slow(tt);
+    if (!all_in_range) {
+        // behind a wave-uniform test and an asm barrier so that the compiler cannot fold the slow path into the
+        // fast one as a select
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {
+            if (!ok) {
+                double tt = t;
+                asm volatile("" : "+v"(tt));
+                p = sat_vapor_pressure_slow(tt);
+            }
         }
     }
     return p;
 }
-XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p) {
-    return EPS * fdiv(es_tab(tb, td), p - es_tab(tb, t));
+XP_DEV bool in_table(double t, double margin) { return (t >= ES_T_LO + margin) && (t < ES_T_LO + (double)ES_N - margin); }
+// ln(x) from the LDS table that follows the e_s table: x = 2^e m, m in [0.5,1) = c_i (1 + r), |r| < 2^-7;
+// ln x = e ln2 + ln c_i + log1p(r), log1p by its series to r^7 (< 2e-18).  Positive finite x (NaN -> NaN).
+XP_DEV double log_tab(const double *tb, double x) {
+    const double *lt = tb + ES_TAB;
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int i = (int)(m * 128.0) - 64;
+    i = i < 0 ? 0 : (i > LOG_N - 1 ? LOG_N - 1 : i);
+    double r = __builtin_fma(m, lt[i], -1.0);
+    double q = 1.0 / 7.0;
+    q = __builtin_fma(q, r, -1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.2);
+    q = __builtin_fma(q, r, -0.25);
+    q = __builtin_fma(q, r, 1.0 / 3.0);
+    q = __builtin_fma(q, r, -0.5);
+    q = __builtin_fma(q, r, 1.0);
+    return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lt[LOG_N + i]));
+}
+XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p, bool fast = false) {
+    return EPS * fdiv(es_tab(tb, td, fast), p - es_tab(tb, t, fast));
 }
 // stage the table (global -> LDS); every thread of the block must call this before any early return
 XP_DEV const double *stage_es_table(const double *g, double *lds) {
-    for (int i = threadIdx.x; i < ES_TAB; i += blockDim.x) lds[i] = g[i];
+    for (int i = threadIdx.x; i < LDS_TAB; i += blockDim.x) lds[i] = g[i];
     __syncthreads();
     return lds;
 }
@@ -205,7 +234,7 @@ XP_DEV double dt_dlnp_e(double p, double t, double e) {
     double den = __builtin_fma(CP_D * rt2, pe, (LV * LV * EPS * EPS) * e);
     return rt2 * fdiv(num, den);
 }
-XP_DEV double dt_dlnp(const double *es, double p, double t) { return dt_dlnp_e(p, t, es_tab(es, t)); }
+XP_DEV double dt_dlnp(const double *es, double p, double t, bool fast) { return dt_dlnp_e(p, t, es_tab(es, t, fast)); }
 
 struct Tables {               // reference-format lookup tables resident in HBM (pf.py:447-523)
     const uint16_t *index;    // [n_p][n_t], 0 = NaN
@@ -241,7 +270,9 @@ struct Moist {
     }
     // temperature of the adiabat at pressure pk (ln pk = xk); levels must come in order of
     // increasing distance from the start point (pressure decreasing upwards)
-    XP_DEV double at(double pk, double xk, const Tables &tb) {
+    // `hoist`: test the e_s table range once per RK4 step (wave-uniform) instead of once per stage: a step moves the
+    // parcel temperature by at most kappa*T*h < 9 K, so 10 K of margin at its start covers all four stages
+    XP_DEV double at(double pk, double xk, const Tables &tb, bool hoist = false) {
         if (dead || isnan_(pk)) return qnan();
         if (table) {
             // (table mode keeps IEEE division: it emulates np.interp on the reference's tables)
@@ -273,12 +304,13 @@ struct Moist {
             for (int s = 0; s < ns; ++s) {
                 double pm = ps * rh;
                 double pe = (s == ns - 1) ? pk : pm * rh;
+                bool fast = hoist && (__builtin_amdgcn_ballot_w64(!in_table(t, 10.0)) == 0ull);
                 double k1 = dt_dlnp_e(ps, t, e);                 // e_s(T) at the current point is already known
-                double k2 = dt_dlnp(es, pm, t + 0.5 * h * k1);
-                double k3 = dt_dlnp(es, pm, t + 0.5 * h * k2);
-                double k4 = dt_dlnp(es, pe, t + h * k3);
+                double k2 = dt_dlnp(es, pm, t + 0.5 * h * k1, fast);
+                double k3 = dt_dlnp(es, pm, t + 0.5 * h * k2, fast);
+                double k4 = dt_dlnp(es, pe, t + h * k3, fast);
                 t = t + (h * (1.0 / 6.0)) * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
-                e = es_tab(es, t);
+                e = es_tab(es, t, fast);
                 ps = pe;
             }
             x = xk; p = pk;
@@ -288,7 +320,11 @@ struct Moist {
 };
 
 // ---- the streaming LFC / EL / CAPE / CIN state machine ------------------------------------------
-// Nodes are the levels of the LCL-augmented profile in order; feed them with node().
+// Nodes are the levels of the LCL-augmented profile in order; feed them with node().  The per-node path is
+// branch-free (selects); everything that happens at most a few times per column -- first node, sign changes,
+// NaN gaps -- sits behind one ballot-guarded branch.
+// Input contract used here (the reference's, README.md:9 / pf.py:2319-2320): pressure decreases with the node
+// index, so "the lowest pressure where both temperatures exist" (pf.py:1143-1147) is the LAST such node.
 struct Scan {
     // configuration
     double p_lcl;
@@ -303,8 +339,7 @@ struct Scan {
     double lfc_p, lfc_t, el_p, el_t;
     int lfc_idx, el_idx;
     bool any_inc, pos_parcel, env_any;
-    // top of column where both temperatures exist (pf.py:1143-1147)
-    double top_p, top_par, top_env, min_p;
+    double top_par, top_env, min_p;
 
     XP_DEV void init(double p_lcl_, bool pos_neg_) {
         p_lcl = p_lcl_; pos_neg = pos_neg_;
@@ -312,58 +347,52 @@ struct Scan {
         cape = cin = cape_lcl = cin_lcl = cape_lfc = cin_lfc = cape_el = 0.0;
         lfc_p = lfc_t = el_p = el_t = qnan(); lfc_idx = el_idx = -1;
         any_inc = pos_parcel = env_any = false;
-        top_p = top_par = top_env = min_p = qnan();
+        top_par = top_env = min_p = qnan();
     }
     XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
         if (pos_neg) { cape += fmax(a, 0.0); cin += fmin(a, 0.0); }      // maxNum/minNum drop a NaN operand
         else { double b = isnan_(a) ? 0.0 : a; cape += b; cin += b; }
     }
-    XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
-        double y = par - env;
-        if (j == 0) {
-            use_all = (env != par);
-        } else {
-            int i = j - 1;
-            // sign(a-b).diff() != 0, NaN counts as flagged (pf.py:1019-1022): same sign <=> y*yp > 0 or both zero
-            bool flagged = !((y * yp > 0.0) || (y == 0.0 && yp == 0.0));
-            bool handled = false;
-            // rare: ballot first, so the crossing arithmetic is not speculated into the per-level path
-            if (__builtin_amdgcn_ballot_w64(flagged) != 0ull && flagged) {
-                double xs = (y * Xp - yp * X) / (y - yp);                       // pf.py:1046
-                double frac = (xs - Xp) / (X - Xp);
-                double zy = frac * (y - yp) + yp;                               // zero crossing of y (pf.py:1225-1231)
-                if (!isnan_(zy)) {                                              // valid zero: two triangles (pf.py:1246-1273)
-                    handled = true;
-                    double ps = exp_slow(xs);                                   // rare path: library exp/log, so that
-                    double zlog = log_slow(ps);                                      // "p* < p_lcl" ties break as on the CPU (pf.py:1237)
-                    add((yp * 0.5) * fabs(Xp - zlog));
-                    double ys = frac * (par - parp) + parp;                     // pf.py:1050
-                    if (!isnan_(ps)) {
-                        bool in_sel = use_all || i >= 1;
-                        if (y > 0.0 && in_sel) {                                // increasing crossing
-                            any_inc = true;
-                            if (ps < p_lcl && !(ps <= lfc_p)) {                 // bottom LFC above the LCL (pf.py:1127-1132)
-                                lfc_p = ps; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
-                            }
-                        }
-                        if (y < 0.0 && i >= 1 && !(ps >= el_p)) {               // top EL (pf.py:1136-1138)
-                            el_p = ps; el_t = ys; el_idx = i; cape_el = cape;
-                        }
-                    }
-                    add((y * 0.5) * fabs(X - zlog));
+    // first node, or an interval whose end points differ in sign / are NaN (pf.py:1019-1022)
+    XP_DEV void special(double X, double par, double env, double y, double a_reg) {
+        if (j == 0) { use_all = (env != par); return; }
+        int i = j - 1;
+        double xs = (y * Xp - yp * X) / (y - yp);                           // pf.py:1046
+        double frac = (xs - Xp) / (X - Xp);
+        double zy = frac * (y - yp) + yp;                                   // zero crossing of y (pf.py:1225-1231)
+        if (isnan_(zy)) { add(a_reg); return; }                             // no valid zero: plain trapezoid (NaN -> skipped)
+        double ps = exp_slow(xs);                                           // library exp/log, so that "p* < p_lcl" ties
+        double zlog = log_slow(ps);                                         // break as on the CPU (pf.py:1237)
+        add((yp * 0.5) * fabs(Xp - zlog));                                  // lower triangle (pf.py:1246-1273)
+        double ys = frac * (par - parp) + parp;                             // pf.py:1050
+        if (!isnan_(ps)) {
+            bool in_sel = use_all || i >= 1;
+            if (y > 0.0 && in_sel) {                                        // increasing crossing
+                any_inc = true;
+                if (ps < p_lcl && !(ps <= lfc_p)) {                         // bottom LFC above the LCL (pf.py:1127-1132)
+                    lfc_p = ps; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
                 }
             }
-            if (!handled) add(fabs(X - Xp) * ((yp + y) * 0.5));                 // pf.py:186-198
-        }
-        if (P < p_lcl && par > env) pos_parcel = true;                          // pf.py:1166-1169
-        if (!isnan_(env)) env_any = true;
-        if (!isnan_(P)) {
-            if (!(P >= min_p)) min_p = P;
-            if (!isnan_(par) && !isnan_(env)) {
-                if (!(P >= top_p)) { top_p = P; top_par = par; top_env = env; }
-                else if (P == top_p) { top_par = fmax(top_par, par); top_env = fmax(top_env, env); }
+            if (y < 0.0 && i >= 1 && !(ps >= el_p)) {                       // top EL (pf.py:1136-1138)
+                el_p = ps; el_t = ys; el_idx = i; cape_el = cape;
             }
         }
+        add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
+    }
+    XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
+        double y = par - env;
+        // same sign <=> y*yp > 0 or both zero; NaN (and the first node, yp = NaN) is "not same"
+        bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
+        double a = fabs(X - Xp) * ((yp + y) * 0.5);                         // pf.py:186-198
+        add(same ? a : 0.0);
+        if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special(X, par, env, y, a);
+        pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
+        env_any = env_any || !isnan_(env);
+        bool pv = !isnan_(P);
+        bool valid = pv && !isnan_(par) && !isnan_(env);
+        min_p = pv ? P : min_p;
+        top_par = valid ? par : top_par;
+        top_env = valid ? env : top_env;
         if (is_lcl) { cape_lcl = cape; cin_lcl = cin; }
         Xp = X; yp = y; parp = par; ++j;
     }

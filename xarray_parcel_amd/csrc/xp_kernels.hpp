@@ -131,7 +131,7 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // and only advances the moist adiabat, so the LCL machinery costs nothing for most of the column.
 template <typename T, int PMODE, bool PROFILE, bool TABLE>
 __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
-    __shared__ double s_es[ES_TAB];
+    __shared__ double s_es[LDS_TAB];
     const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
@@ -169,7 +169,13 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
 
     const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
     const double w_parcel = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0; // pf.py:748
-    const double x0 = flog(pc.p), x_lcl = log(l.p);
+    // ln p bookkeeping.  Levels use the table logarithm; the LCL node uses the library log (its crossing tests
+    // "p* < p_lcl" then break ties as on the CPU); a level that sits exactly on the LCL pressure takes the LCL's
+    // value so that the interval between the two stays zero-width; and the parcel's own ln p (x0) is whatever its
+    // level gets, so that the surface parcel reproduces its level bit for bit (T0 * exp(0)) -- the reference's lfc_el
+    // branches on that exact equality (pf.py:1117-1120).
+    const double x_lcl = log(l.p);
+    const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
 
     Scan sc; sc.init(l.p, a.pos_neg != 0);
     Moist m; m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
@@ -215,14 +221,17 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     };
     // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
     auto moist_node = [&](double P, double X, double T_, double Td_) __attribute__((always_inline)) {
-        double tp = m.at(P, X, a.tb);                                      // NaN pressure -> NaN
+        // one wave-uniform range test per level instead of one per e_s evaluation
+        bool fast = __builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull;
+        double tp = m.at(P, X, a.tb, true);                                // NaN pressure -> NaN
         double w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;                  // pf.py:760
         double tvp = need_w ? virt(tp, w) : tp;
-        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
+        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P, fast)) : T_;   // pf.py:839-843
         emit(P, X, tp, tvp, T_, tve, Td_, false);
     };
     auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
-        double X = flog(P);
+        double X = log_tab(es, P);
+        X = (P == l.p) ? x_lcl : X;
         if (isnan_(P) && !lcl_done) status |= 4;                           // NaN pressure below the LCL (see xparcel.h)
         if (!lcl_done && P < l.p) emit_lcl(P, X, T_, Td_);
         // lanes of one wavefront sit on both sides of their LCLs here: only the parcel temperature / mixing ratio
@@ -231,13 +240,24 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
             tp = pc.t * fexp(KAPPA * (X - x0));
             w = w_parcel;
-            if (need_w && P == l.p) { double ta = m.at(P, X, a.tb); w = mix_of_e(TABLE ? es_tab(es, ta) : m.e, P); }   // pf.py:773 (<=)
         } else {
             tp = m.at(P, X, a.tb);
             w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;
         }
         double tvp = need_w ? virt(tp, w) : tp;
         double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
+        // A level exactly ON the LCL pairs the dry temperature with the saturation mixing ratio at the moist-adiabat
+        // temperature (pf.py:773 uses <=).  For a saturated parcel this is the parcel's own level and the sign of
+        // parcel-minus-environment there is rounding noise of the reference's expressions, so these (rare) nodes
+        // evaluate them in its operation order with library math.
+        bool on_lcl = need_w && (P == l.p);
+        if (__builtin_amdgcn_ballot_w64(on_lcl) != 0ull && on_lcl) {
+            double ta = m.at(P, X, a.tb);
+            asm volatile("" : "+v"(ta));
+            double ea = es_ref(ta);
+            tvp = tp * (1.0 + VT_EPS * (EPS * ea / (P - ea)));
+            tve = virt_ref(T_, Td_, P);
+        }
         emit(P, X, tp, tvp, T_, tve, Td_, false);
         if (!isnan_(P) && !lcl_done) { pb = P; xb = X; tb_ = T_; tdb = Td_; }
     };
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
         double P = np_, T_ = nt_, Td_ = ntd_;
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
-        moist_node(P, flog(P), T_, Td_);
+        moist_node(P, log_tab(es, P), T_, Td_);
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (PROFILE) {
@@ -340,7 +360,7 @@ void k_dry_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void
 template <typename T> __global__ __launch_bounds__(256)
 void k_moist_lapse(View pv, int64_t nlev, int64_t ncol, const void *pt, const void *pp, int table_mode, Tables tb,
                    const double *es_g, OutView out) {
-    __shared__ double s_es[ES_TAB];
+    __shared__ double s_es[LDS_TAB];
     const double *es = stage_es_table(es_g, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
@@ -366,7 +386,7 @@ template <typename T> __global__ __launch_bounds__(256)
 void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const void *pt, const void *ptd,
                       int table_mode, Tables tb, const double *es_g, OutView ot, OutView otv, void *olp, void *olt,
                       void *oltv) {
-    __shared__ double s_es[ES_TAB];
+    __shared__ double s_es[LDS_TAB];
     const double *es = stage_es_table(es_g, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;

@@ -68,6 +68,13 @@ void build_es_table(double *out) {
         }
         for (int j = 0; j < n; ++j) out[j * xp::ES_N + i] = (double)(A[j][n] / A[j][j]);
     }
+    // ln table for xp::log_tab: mantissa interval i of [0.5, 1) has centre c_i = (i + 64.5) / 128
+    double *lt = out + xp::ES_TAB;
+    for (int i = 0; i < xp::LOG_N; ++i) {
+        LD c = ((LD)i + 64.5L) / 128.0L;
+        lt[i] = (double)(1.0L / c);
+        lt[xp::LOG_N + i] = (double)logl(c);
+    }
 }
 
 // Stages host buffers through device scratch for one call; device buffers pass through.
@@ -228,10 +235,10 @@ int xp_init(int device) {
     }
     if (g.init && g.device != device && g.es_tab) { (void)hipFree(g.es_tab); g.es_tab = nullptr; }
     if (!g.es_tab) {
-        std::vector<double> tab(xp::ES_TAB);
+        std::vector<double> tab(xp::LDS_TAB);
         build_es_table(tab.data());
-        HIP_TRY(hipMalloc((void **)&g.es_tab, sizeof(double) * xp::ES_TAB));
-        HIP_TRY(hipMemcpy(g.es_tab, tab.data(), sizeof(double) * xp::ES_TAB, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&g.es_tab, sizeof(double) * xp::LDS_TAB));
+        HIP_TRY(hipMemcpy(g.es_tab, tab.data(), sizeof(double) * xp::LDS_TAB, hipMemcpyHostToDevice));
     }
     g.device = device;
     g.init = true;
