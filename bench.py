@@ -31,6 +31,22 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
     return 3 * nlev * itemsize + n_out * itemsize
 
 
+def measured_traffic(nlev, ny, nx, dtype):
+    """HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE / WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes; see the JSON's note).  bench.py cannot run the profiler on itself,
+    so this is the number measured on the same command at the time the profile was taken; None for any other shape."""
+    import glob
+    if (nlev, ny, nx, dtype) != (NLEV, NY, NX, 'f64'):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))['hbm_traffic_bytes'])
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed, nlev, sample_cols):
     import numpy as np
     from oracle import c_oracle
@@ -142,8 +158,8 @@ def main():
                        'columns_per_gpu': ncol, 'levels': a.nlev,
                        'multi_gpu': 'y-slab per rank + one RCCL gather of (cape, cin) per step' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'xp::k_cape_cin<double, surface, no-profile>' if a.dtype == 'f64' else 'xp::k_cape_cin<float, surface, no-profile>',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a.nlev, a.ny, a.nx, a.dtype),
+                         'kernel': 'xp::k_cape_cin<double, 0, false, false>' if a.dtype == 'f64' else 'xp::k_cape_cin<float, 0, false, false>',
                          'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch},
             'check': {'max_cape': float(last['cape'].max()), 'min_cin': float(last['cin'].min())},
         }
