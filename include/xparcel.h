@@ -186,6 +186,20 @@ int xp_select_parcel(const xp_view *pressure, const xp_view *temperature, const 
 /* pf.py:137-162 mixed_layer: pressure-weighted layer mean of one variable over the lowest `depth` hPa. */
 int xp_mixed_layer(const xp_view *pressure, const xp_view *variable, double depth, void *out, void *stream);
 
+/* --- SURVEY 8(f) "next" items built on the same device code ------------------------------------------ */
+
+/* pf.py:389-445 wet_bulb_temperature (Normand's rule): for every element, lift to the LCL (pf.py:609) and come back down
+   the moist adiabat to the element's own pressure (pf.py:525).  out has the layout of `pressure`. */
+int xp_wet_bulb_temperature(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint,
+                            int32_t moist_mode, void *out, void *stream);
+
+/* pf.py:1758-1811 linear_interp / pf.py:1813-1828 log_interp: value of `variable` at coordinate `at` (one value per
+   column, or a single value for all when at_is_scalar) between the bracketing levels of `coords`; duplicates of a
+   bracketing coordinate are averaged, no extrapolation (NaN).  log_coords != 0 interpolates in ln(coords), ln(at).
+   Used by lifted_index (pf.py:1722), deep_convective_index (pf.py:1830), isobar_temperature (pf.py:2193). */
+int xp_interp_level(const xp_view *coords, const xp_view *variable, const void *at, int32_t at_is_scalar,
+                    int32_t log_coords, void *out, void *stream);
+
 const char *xp_last_error(void);
 
 #ifdef __cplusplus

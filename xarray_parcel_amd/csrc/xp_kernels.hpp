@@ -480,4 +480,54 @@ void k_cape_cin_base(View pv, View envv, View parv, int64_t nlev, int64_t ncol, 
     st(cape, f64, c, RD * sc_); st(cin, f64, c, cin_v);
 }
 
+// wet_bulb_temperature (pf.py:389-445): one thread per (level, column) element
+template <typename T> __global__ __launch_bounds__(256)
+void k_wet_bulb(View pv, View tv, View tdv, int64_t nlev, int64_t ncol, int table_mode, Tables tb, const double *es_g,
+                OutView out) {
+    __shared__ double s_es[LDS_TAB];
+    const double *es = stage_es_table(es_g, s_es);
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nlev * ncol) return;
+    int64_t k = e / ncol, c = e - k * ncol;
+    double p = ld<T>(pv, k, c), t = ld<T>(tv, k, c), td = ld<T>(tdv, k, c);
+    Lcl l = lcl(p, t, td);                                                 // pf.py:420-422
+    Moist m; m.start(es, l.p, log(l.p), l.t, table_mode != 0, tb);
+    double r = qnan();
+    if (!isnan_(p)) {
+        if (p == l.p) r = m.at(p, m.x, tb);                                // saturated: LCL snapped onto the element
+        else r = m.at(p, log(p), tb);                                      // pf.py:425-428 (moist descent, p > p_lcl)
+    }
+    st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, r);
+}
+
+// linear_interp / log_interp (pf.py:1758-1828) of one variable at one coordinate per column; no ordering assumed
+template <typename T> __global__ __launch_bounds__(256)
+void k_interp_level(View cv, View xv, int64_t nlev, int64_t ncol, const void *at_p, int at_scalar, int log_coords,
+                    void *out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double at = ld1<T>(at_p, at_scalar ? 0 : c);
+    if (log_coords) at = log(at);
+    // coords_before = smallest coordinate >= at, coords_after = largest <= at (pf.py:1774-1775); values = mean over
+    // the levels that carry exactly that coordinate, skipping NaN (pf.py:1798-1799)
+    double cb = qnan(), ca = qnan(), sb = 0.0, sa = 0.0;
+    int nb = 0, na = 0;
+    for (int64_t k = 0; k < nlev; ++k) {
+        double cc = ld<T>(cv, k, c), x = ld<T>(xv, k, c);
+        if (log_coords) cc = log(cc);
+        if (isnan_(cc)) continue;
+        if (cc >= at) {
+            if (!(cc >= cb)) { cb = cc; sb = 0.0; nb = 0; }
+            if (cc == cb && !isnan_(x)) { sb += x; ++nb; }
+        }
+        if (cc <= at) {
+            if (!(cc <= ca)) { ca = cc; sa = 0.0; na = 0; }
+            if (cc == ca && !isnan_(x)) { sa += x; ++na; }
+        }
+    }
+    double xb = nb ? sb / (double)nb : qnan(), xa = na ? sa / (double)na : qnan();
+    double res = xb + (xa - xb) * ((at - cb) / (ca - cb));
+    st(out, sizeof(T) == 8, c, (xb == xa) ? xb : res);                     // pf.py:1802-1806
+}
+
 }  // namespace xp

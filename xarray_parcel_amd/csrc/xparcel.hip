@@ -466,4 +466,49 @@ int xp_cape_cin_base(const xp_view *p, const xp_view *env, const xp_view *par, c
     return st.finish();
 }
 
+int xp_wet_bulb_temperature(const xp_view *p, const xp_view *t, const xp_view *td, int32_t moist_mode, void *out,
+                            void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(td, "dewpoint")) ||
+        (rc = same_shape(p, t, "pressure/temperature")) || (rc = same_shape(p, td, "pressure/dewpoint"))) return rc;
+    if (!out) return fail(XP_E_ARG, "xp_wet_bulb_temperature: null output");
+    if (moist_mode == XP_MOIST_TABLE && !g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
+    Stager st(stream);
+    xp::View pv, tv, tdv; xp::OutView ov;
+    void *od;
+    if ((rc = stage_view(st, p, &pv)) || (rc = stage_view(st, t, &tv)) || (rc = stage_view(st, td, &tdv)) ||
+        (rc = st.out(out, (size_t)p->nlev * (size_t)p->ncol * esize(p->dtype), p->mem, &od))) return rc;
+    ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
+    xp::Tables tb = g.tb;
+    int tm = moist_mode == XP_MOIST_TABLE;
+    int64_t n = p->nlev * p->ncol;
+    if (n) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_wet_bulb<double>), dim3(blocks(n)), dim3(256), 0, st.s, pv, tv, tdv, p->nlev, p->ncol, tm, tb, (const double *)g.es_tab, ov);
+        else hipLaunchKernelGGL((xp::k_wet_bulb<float>), dim3(blocks(n)), dim3(256), 0, st.s, pv, tv, tdv, p->nlev, p->ncol, tm, tb, (const double *)g.es_tab, ov);
+    }
+    return st.finish();
+}
+
+int xp_interp_level(const xp_view *coords, const xp_view *x, const void *at, int32_t at_is_scalar, int32_t log_coords,
+                    void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(coords, "coords")) || (rc = check_view(x, "variable")) || (rc = same_shape(coords, x, "coords/variable"))) return rc;
+    if (!at || !out) return fail(XP_E_ARG, "xp_interp_level: null argument");
+    Stager st(stream);
+    xp::View cv, xv;
+    const void *da;
+    void *od;
+    size_t cb = (size_t)coords->ncol * esize(coords->dtype);
+    if ((rc = stage_view(st, coords, &cv)) || (rc = stage_view(st, x, &xv)) ||
+        (rc = st.in(at, at_is_scalar ? esize(coords->dtype) : cb, coords->mem, &da)) ||
+        (rc = st.out(out, cb, coords->mem, &od))) return rc;
+    if (coords->ncol) {
+        if (coords->dtype == XP_F64) hipLaunchKernelGGL((xp::k_interp_level<double>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
+        else hipLaunchKernelGGL((xp::k_interp_level<float>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
+    }
+    return st.finish();
+}
+
 }  // extern "C"

@@ -377,3 +377,37 @@ def cape_cin_base(pressure, temperature, lfc_pressure, el_pressure, parcel_tempe
                                  C.byref(_view(par, nlev, ncol)), C.c_void_p(lf.ptr), C.c_void_p(el.ptr), C.byref(o),
                                  C.c_void_p(cptr), C.c_void_p(nptr), _stream(dev)))
     return {'cape': cape.reshape(hshape), 'cin': cin.reshape(hshape)}
+
+
+# ---- SURVEY 8(f) items that reuse the hot-path device code -------------------------------------------------
+def wet_bulb_temperature(pressure, temperature, dewpoint, moist=None):
+    """pf.py:389: Normand's rule, every element independently."""
+    (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    out, optr = _alloc((nlev, ncol), dt, dev, p)
+    L.check(lib.xp_wet_bulb_temperature(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)),
+                                        C.byref(_view(td, nlev, ncol)), C.c_int32(L.MOIST[moist or _DEFAULT['moist']]),
+                                        C.c_void_p(optr), _stream(dev)))
+    return out.reshape((nlev,) + hshape)
+
+
+def interp_level(coords, variable, at, log=False):
+    """pf.py:1758 linear_interp (log=False) / pf.py:1813 log_interp (log=True) of one variable."""
+    (cds, x), dt, dev = _common(coords, variable)
+    nlev, ncol, hshape = _vert_shape(cds)
+    lib = L.init(_device_of(cds))
+    scalar = np.ndim(at) == 0 and not _is_torch(at)
+    ah = _Arr(torch.as_tensor(np.asarray([at], dtype=dt)).to(cds.t.device) if dev else np.asarray([at], dtype=dt),
+              dtype=dt) if scalar else _per_col(at, ncol, dt, dev, cds)
+    out, optr = _alloc((ncol,), dt, dev, cds)
+    L.check(lib.xp_interp_level(C.byref(_view(cds, nlev, ncol)), C.byref(_view(x, nlev, ncol)), C.c_void_p(ah.ptr),
+                                C.c_int32(int(scalar)), C.c_int32(int(log)), C.c_void_p(optr), _stream(dev)))
+    return out.reshape(hshape)
+
+
+def lifted_index(profile):
+    """pf.py:1722: environment minus parcel temperature at 500 hPa (log-p interpolation of the profile)."""
+    env = interp_level(profile['pressure'], profile['environment_temperature'], 500.0, log=True)
+    par = interp_level(profile['pressure'], profile['temperature'], 500.0, log=True)
+    return env - par

@@ -301,6 +301,49 @@ def mixed_layer(dat, depth=100, vert_dim=VERT):
     return Dataset({k: _horiz(_np(v), dims, coords, name=k) for k, v in r.items()})
 
 
+# -- SURVEY 8(f) items on the same kernels ------------------------------------------------------------------------
+def wet_bulb_temperature(pressure, temperature, dewpoint, vert_dim=VERT):
+    """pf.py:389."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    t, _, _, _ = _split(temperature, vert_dim)
+    td, _, _, _ = _split(dewpoint, vert_dim)
+    out = _np(_api.wet_bulb_temperature(p, t, td))
+    if vc is None:
+        return _horiz(out.reshape(p.shape), dims, coords, name='wet_bulb_temperature',
+                      attrs={'long_name': 'Wet bulb temperature', 'units': 'K'})
+    return _vert(out, vert_dim, vc, dims, coords, name='wet_bulb_temperature',
+                 attrs={'long_name': 'Wet bulb temperature', 'units': 'K'})
+
+
+def log_interp(x, coords, at, dim=VERT):
+    """pf.py:1813 for one DataArray `x`."""
+    cv, dims, hcoords, _ = _split(coords, dim)
+    xv, _, _, _ = _split(x, dim)
+    return _horiz(_np(_api.interp_level(cv, xv, np.asarray(getattr(at, 'values', at)), log=True)), dims, hcoords,
+                  attrs=dict(getattr(x, 'attrs', {})))
+
+
+def linear_interp(x, coords, at, dim=VERT, keep_attrs=True, extrapolate=False):
+    """pf.py:1758 for one DataArray `x` (extrapolate=False only)."""
+    assert not extrapolate, 'extrapolation is not part of the MI355X path'
+    cv, dims, hcoords, _ = _split(coords, dim)
+    xv, _, _, _ = _split(x, dim)
+    return _horiz(_np(_api.interp_level(cv, xv, np.asarray(getattr(at, 'values', at)), log=False)), dims, hcoords,
+                  attrs=dict(getattr(x, 'attrs', {})) if keep_attrs else {})
+
+
+def lifted_index(profile, vert_dim=VERT, description=None, prefix=None):
+    """pf.py:1722."""
+    p, dims, coords, _ = _split(profile['pressure'], vert_dim)
+    prof = {'pressure': p, 'temperature': _split(profile['temperature'], vert_dim)[0],
+            'environment_temperature': _split(profile['environment_temperature'], vert_dim)[0]}
+    attrs = {'long_name': 'Lifted index', 'units': 'K'}
+    if description is not None:
+        attrs['description'] = description
+    name = 'lifted_index' if prefix is None else prefix + '_lifted_index'
+    return Dataset({name: _horiz(_np(_api.lifted_index(prof)), dims, coords, attrs=attrs, name=name)})
+
+
 # -- tables (pf.py:39-61) ------------------------------------------------------------------------------
 def load_moist_adiabat_lookups(**kwargs):
     """pf.py:39: make the reference-format lookup tables available to moist='table' calls."""
