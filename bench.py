@@ -87,18 +87,27 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    # Rehearsal knobs (not used by the driver): XPARCEL_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # XPARCEL_BENCH_BACKEND=gloo gathers through host memory, so the N > 1 control flow can be exercised on a 1-GPU box.
+    single = os.environ.get('XPARCEL_BENCH_SINGLE_DEVICE') == '1'
+    backend = os.environ.get('XPARCEL_BENCH_BACKEND', 'nccl')
+    local = 0 if single else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')       # where the gather buffers live
 
     tdt = torch.float64 if a.dtype == 'f64' else torch.float32
     ncol = a.ny * a.nx
     p, t, td = synth.columns_torch(a.nlev, ncol, dev, seed=20250719, dtype=tdt, col_offset=rank * ncol)
     want = ('cape', 'cin')
     side = torch.cuda.Stream(device=dev) if world > 1 else None
-    gathered = [torch.empty((world, 2, ncol), dtype=tdt, device=dev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty((world, 2, ncol), dtype=tdt, device=cdev) for _ in range(2)] if (world > 1 and rank == 0) else None
     sendbuf = [torch.empty((2, ncol), dtype=tdt, device=dev) for _ in range(2)] if world > 1 else None
     kernel_ms = []
 
@@ -116,7 +125,11 @@ def main():
             with torch.cuda.stream(side):
                 sendbuf[b][0].copy_(r['cape'])
                 sendbuf[b][1].copy_(r['cin'])
-                dist.gather(sendbuf[b], list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)
+                src = sendbuf[b]
+                if backend != 'nccl':
+                    side.synchronize()
+                    src = src.cpu()
+                dist.gather(src, list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)
             r['cape'].record_stream(side)
             r['cin'].record_stream(side)
         return r
@@ -138,7 +151,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -17,8 +17,7 @@
  *     (k, c) of a view lives at data[k*lev_stride + c*col_stride] (strides in
  *     elements).  col_stride == 1 (the (lev, y, x) C-order layout) is the coalesced
  *     fast path; anything else is correct but slower;
- *   - dtype is XP_F32 or XP_F64 for data in memory; arithmetic is fp64 unless
- *     xp_opts.compute says otherwise;
+ *   - dtype is XP_F32 or XP_F64 for data in memory; arithmetic is fp64;
  *   - mem says where a buffer lives: XP_MEM_DEVICE pointers are used in place,
  *     XP_MEM_HOST buffers are staged through internal device scratch (PCIe time
  *     is then part of the call);
@@ -93,7 +92,7 @@ typedef struct {
     int32_t pos_cape_neg_cin;               /* default 1 (pf.py:1293) */
     int32_t post_zero_cin;                  /* default 0 (pf.py:1293) */
     int32_t moist_mode;                     /* XP_MOIST_* */
-    int32_t compute;                        /* XP_F64 (default) | XP_F32 (fast path for fp32 data) */
+    int32_t compute;                        /* arithmetic type: XP_F64 (the only one implemented; XP_F32 is rejected with XP_E_ARG) */
     int32_t reserved[2];
 } xp_opts;
 

@@ -251,3 +251,33 @@ def test_wet_bulb_and_interp_vs_oracle():
         for c in range(p.shape[1]):
             r = (po.log_interp if log else po.linear_interp)(t[:, c], p[:, c], at[c])
             assert (np.isnan(g[c]) and np.isnan(r)) or abs(g[c] - r) <= 1e-10, (log, c, g[c], r)
+
+
+def test_strided_device_views_through_the_raw_abi():
+    """include/xparcel.h promises general element strides: feed (ncol, nlev)-major device arrays (lev_stride = 1,
+    col_stride = nlev) straight to xp_cape_cin and compare with the dense call."""
+    import ctypes as C
+    import torch
+    from xarray_parcel_amd import _lib as L
+    nlev, ncol = 24, 1000
+    p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=9, nan_fraction=0.05, dtype=np.float64)
+    dense = xa.cape_cin_columns(p, t, td, want=('cape', 'cin', 'lfc_index'))
+    lib = L.init(0)
+    dev = [torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (p, t, td)]            # (ncol, nlev)
+    views = [L.View(x.data_ptr(), L.XP_F64, L.XP_MEM_DEVICE, nlev, ncol, 1, nlev) for x in dev]
+    cape = torch.empty(ncol, dtype=torch.float64, device='cuda')
+    cin = torch.empty_like(cape)
+    idx = torch.empty(ncol, dtype=torch.int32, device='cuda')
+    so = L.ScalarsOut()
+    so.dtype, so.mem = L.XP_F64, L.XP_MEM_DEVICE
+    so.cape, so.cin, so.lfc_index = cape.data_ptr(), cin.data_ptr(), idx.data_ptr()
+    pc = L.Parcel(L.PARCEL['surface'], 0, 0.0, None, None, None)
+    o = L.Opts(1, 1, 1, 0, 0, L.XP_F64, (C.c_int32 * 2)(0, 0))
+    L.check(lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o),
+                            C.byref(so), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(cape.cpu().numpy(), dense['cape']) and np.array_equal(cin.cpu().numpy(), dense['cin'])
+    assert np.array_equal(idx.cpu().numpy(), dense['lfc_index'])
+    o32 = L.Opts(1, 1, 1, 0, 0, L.XP_F32, (C.c_int32 * 2)(0, 0))
+    assert lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o32),
+                           C.byref(so), None, None) == -1                 # XP_E_ARG: fp32 arithmetic not implemented

@@ -202,6 +202,7 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
         if (o->lcl_interp != XP_LCL_INTERP_LINEAR && o->lcl_interp != XP_LCL_INTERP_LOG)
             return fail(XP_E_INTERP, "interpolator must be linear or log");
         if (o->moist_mode != XP_MOIST_EXACT && o->moist_mode != XP_MOIST_TABLE) return fail(XP_E_ARG, "bad moist_mode");
+        if (o->compute != XP_F64) return fail(XP_E_ARG, "xp_opts.compute: only XP_F64 arithmetic is implemented");
         a->vtc = o->virtual_temperature_correction; a->log_interp = o->lcl_interp == XP_LCL_INTERP_LOG;
         a->pos_neg = o->pos_cape_neg_cin; a->post_zero = o->post_zero_cin; a->table_mode = o->moist_mode == XP_MOIST_TABLE;
     } else {
