@@ -40,7 +40,7 @@ typedef struct {
     int32_t pos_cape_neg_cin;  /* pf.py:1293 */
     int32_t post_zero_cin;     /* pf.py:1293 */
     int32_t parcel_mode;       /* 0 surface, 1 most unstable, 2 mixed layer, 3 explicit */
-    int32_t moist_mode;        /* 0 rk4 spec, 1 reference lookup tables */
+    int32_t moist_mode;        /* 0 rk4 spec, 1 reference lookup tables, 2 adiabat family (oracle/family.py) */
     double depth;              /* hPa; MU default 300 (pf.py:1558), ML default 100 (pf.py:1652) */
 } xpo_opts;
 
@@ -186,8 +186,117 @@ static void moist_lapse_table(int n, const double *p, double t0, double pref, do
     }
 }
 
+/* ---- "adiabat family" exact mode (specification: oracle/family.py) ------------------------------------------- */
+#define FAM_XLO 3.4011973816621555 /* ln 30 */
+#define FAM_DX 0.028
+#define FAM_NX 133
+#define FAM_SLO 215.0
+#define FAM_DS 0.5
+#define FAM_NS 201
+#define FAM_X1000 6.907755278982137
+#define FAM_SUB 8
+static double *g_fam = NULL;
+
+static void fam_build(double *tab) {
+    int i_up = (int)floor((FAM_X1000 - FAM_XLO) / FAM_DX);
+    for (int j = 0; j < FAM_NS; j++) {
+        for (int dir = -1; dir <= 1; dir += 2) {
+            double t = FAM_SLO + FAM_DS * j, x = FAM_X1000;
+            for (int i = (dir < 0 ? i_up : i_up + 1); i >= 0 && i < FAM_NX; i += dir) {
+                double x1 = FAM_XLO + FAM_DX * i, h = (x1 - x) / FAM_SUB;
+                for (int s = 0; s < FAM_SUB; s++) {
+                    double k1 = dt_dlnp(x, t);
+                    double k2 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
+                    double k3 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
+                    double k4 = dt_dlnp(x + h, t + h * k3);
+                    t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+                    x = x + h;
+                }
+                x = x1;
+                tab[(size_t)i * FAM_NS + j] = t;
+            }
+        }
+    }
+}
+const double *xpo_family_table(void) {
+    if (!g_fam) { g_fam = (double *)malloc(sizeof(double) * FAM_NX * FAM_NS); fam_build(g_fam); }
+    return g_fam;
+}
+static void lagrange6(double t, double *w) {
+    double a = t + 2.0, b = t + 1.0, c = t, d = t - 1.0, e = t - 2.0, g = t - 3.0;
+    w[0] = -(b * c * d * e * g) / 120.0; w[1] = (a * c * d * e * g) / 24.0; w[2] = -(a * b * d * e * g) / 12.0;
+    w[3] = (a * b * c * e * g) / 12.0; w[4] = -(a * b * c * d * g) / 24.0; w[5] = (a * b * c * d * e) / 120.0;
+}
+static void dlagrange6(double t, double *w) {
+    const double n[6] = {-2, -1, 0, 1, 2, 3}, den[6] = {-120, 24, -12, 12, -24, 120};
+    for (int k = 0; k < 6; k++) {
+        double s = 0;
+        for (int skip = 0; skip < 6; skip++) {
+            if (skip == k) continue;
+            double prod = 1;
+            for (int m = 0; m < 6; m++) if (m != k && m != skip) prod *= (t - n[m]);
+            s += prod;
+        }
+        w[k] = s / den[k];
+    }
+}
+static int fam_x_ok(double x) { double i = floor((x - FAM_XLO) / FAM_DX); return i - 2 >= 0 && i + 3 <= FAM_NX - 1; }
+static int fam_s_ok(double s) { double j = floor((s - FAM_SLO) / FAM_DS); return j - 2 >= 0 && j + 3 <= FAM_NS - 1; }
+static double fam_eval(const double *tab, double x, double psi) {
+    if (!(isfinite(x) && isfinite(psi)) || !fam_x_ok(x) || !fam_s_ok(psi)) return NAN;
+    double ux = (x - FAM_XLO) / FAM_DX, us = (psi - FAM_SLO) / FAM_DS;
+    int i = (int)floor(ux), j = (int)floor(us);
+    double wx[6], ws[6], r = 0;
+    lagrange6(ux - i, wx); lagrange6(us - j, ws);
+    for (int b = 0; b < 6; b++) {
+        double row = 0;
+        for (int a = 0; a < 6; a++) row += tab[(size_t)(i - 2 + b) * FAM_NS + (j - 2 + a)] * ws[a];
+        r += wx[b] * row;
+    }
+    return r;
+}
+static double fam_label(const double *tab, double x_lcl, double t_lcl) {
+    if (!(isfinite(x_lcl) && isfinite(t_lcl)) || !fam_x_ok(x_lcl)) return NAN;
+    double lo = FAM_SLO + 2.0 * FAM_DS, hi = FAM_SLO + FAM_DS * (FAM_NS - 3) - 1e-9;
+    double psi = t_lcl + dt_dlnp(x_lcl, t_lcl) * (FAM_X1000 - x_lcl);
+    psi = psi < lo ? lo : (psi > hi ? hi : psi);
+    double ux = (x_lcl - FAM_XLO) / FAM_DX;
+    int i = (int)floor(ux);
+    double wx[6]; lagrange6(ux - i, wx);
+    for (int it = 0; it < 12; it++) {
+        double us = (psi - FAM_SLO) / FAM_DS; int j = (int)floor(us);
+        double ws[6], dws[6], fv = 0, dv = 0;
+        lagrange6(us - j, ws); dlagrange6(us - j, dws);
+        for (int a = 0; a < 6; a++) {
+            double col = 0;
+            for (int b = 0; b < 6; b++) col += wx[b] * tab[(size_t)(i - 2 + b) * FAM_NS + (j - 2 + a)];
+            fv += col * ws[a]; dv += col * dws[a];
+        }
+        fv -= t_lcl; dv /= FAM_DS;
+        double nw = psi - fv / dv;
+        nw = nw < lo ? lo : (nw > hi ? hi : nw);
+        int done = fabs(nw - psi) < 1e-10;
+        psi = nw;
+        if (done) break;
+    }
+    if (!(fabs(fam_eval(tab, x_lcl, psi) - t_lcl) <= 1e-8)) return NAN;
+    return psi;
+}
+static void moist_lapse_family(int n, const double *p, double t0, double pref, double *out) {
+    const double *tab = xpo_family_table();
+    double psi = (pref > 0) ? fam_label(tab, log(pref), t0) : NAN;
+    int ok = !isnan(psi);
+    for (int k = 0; k < n && ok; k++) {
+        if (isnan(p[k])) { out[k] = NAN; continue; }
+        out[k] = (p[k] == pref) ? t0 : fam_eval(tab, log(p[k]), psi);
+        if (isnan(out[k])) ok = 0;
+    }
+    if (!ok) moist_lapse_rk4(n, p, t0, pref, out);      /* label or a level outside the table: whole parcel by RK4 */
+}
+
 void xpo_moist_lapse(int n, const double *p, double t0, double pref, int moist_mode, double *out) {
     if (moist_mode == 1) moist_lapse_table(n, p, t0, pref, out);
+    else if (moist_mode == 2) moist_lapse_family(n, p, t0, pref, out);
     else moist_lapse_rk4(n, p, t0, pref, out);
 }
 

@@ -61,7 +61,7 @@ def _p(a):
 
 
 PARCEL_MODES = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
-MOIST_MODES = {'rk4': 0, 'table': 1}
+MOIST_MODES = {'rk4': 0, 'table': 1, 'family': 2}
 _keep = []
 
 
@@ -110,6 +110,14 @@ def cape_cin_grid(p, t, td, parcel_values=None, want_profile=False, nthreads=0, 
     if want_profile:
         out['profile'] = {k: prof[i] for i, k in enumerate(PROFILE)}
     return out
+
+
+def family_table():
+    """The C oracle's adiabat-family table as a (NX, NS) float64 array (see oracle/family.py)."""
+    from . import family as fam
+    lib().xpo_family_table.restype = DP
+    ptr = lib().xpo_family_table()
+    return np.ctypeslib.as_array(ptr, shape=(fam.NX, fam.NS)).copy()
 
 
 def max_threads():

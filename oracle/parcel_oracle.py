@@ -29,7 +29,7 @@ _MOIST = {'mode': 'ode', 'tables': None}
 
 def set_moist_lapse(mode, tables=None):
     """Select the moist-adiabat implementation used by moist_lapse()."""
-    assert mode in ('ode', 'rk4', 'table')
+    assert mode in ('ode', 'rk4', 'table', 'family')
     _MOIST['mode'] = mode
     if tables is not None:
         _MOIST['tables'] = tables
@@ -334,6 +334,9 @@ def moist_lapse(pressure, parcel_temperature, parcel_pressure=None, moist=None):
         return th.moist_lapse_ode(p, parcel_temperature, parcel_pressure)
     if mode == 'rk4':
         return th.moist_lapse_rk4(p, parcel_temperature, parcel_pressure)
+    if mode == 'family':
+        from . import family
+        return family.moist_lapse_family(p, parcel_temperature, parcel_pressure)
     from . import tables
     return tables.moist_lapse_table(_MOIST['tables'], p, parcel_temperature, parcel_pressure)
 
