@@ -73,6 +73,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0, help='columns for the CPU baseline (0 = auto)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--moist', default='exact', choices=['exact', 'family'],
+                    help='exact = RK4 stepper; family = same ODE from the adiabat-family table (xparcel.h)')
     ap.add_argument('--nlev', type=int, default=NLEV)
     ap.add_argument('--ny', type=int, default=NY)
     ap.add_argument('--nx', type=int, default=NX)
@@ -115,7 +117,7 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = xa.cape_cin_columns(p, t, td, want=want)
+        r = xa.cape_cin_columns(p, t, td, want=want, moist=a.moist)
         e1.record()
         if timed:
             kernel_ms.append((e0, e1))
@@ -167,7 +169,7 @@ def main():
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': f'c2: synthetic {a.nlev}-level x {a.ny} x {a.nx} {a.dtype} soundings per GPU, '
-                                   'surface_based_cape_cin (CAPE/CIN only), exact moist mode, inputs resident in HBM',
+                                   f'surface_based_cape_cin (CAPE/CIN only), exact moist mode ({a.moist}), inputs resident in HBM',
                        'columns_per_gpu': ncol, 'levels': a.nlev,
                        'multi_gpu': 'y-slab per rank + one RCCL gather of (cape, cin) per step' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

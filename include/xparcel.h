@@ -49,7 +49,12 @@ enum { XP_PARCEL_SURFACE = 0, XP_PARCEL_MOST_UNSTABLE = 1, XP_PARCEL_MIXED_LAYER
    KATs are run with, unit_tests.py:114-140) by RK4 in ln p with steps <= 0.1;
    XP_MOIST_TABLE emulates the reference's lookup tables (pf.py:525-607) against tables given
    to xp_set_tables(). */
-enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1 };
+enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1, XP_MOIST_FAMILY = 2 };
+/* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a table of its solutions T(ln p ; theta_w) built at
+   xp_init and interpolated 6 x 6 (within 1.4e-6 K of the ODE, the RK4 stepper of XP_MOIST_EXACT within 2e-5 K); about
+   a third fewer fp64 instructions per level.  Columns whose label or levels leave the table (theta_w outside
+   216..314 K, p outside 32..1110 hPa) are transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the
+   component entry points treat it as XP_MOIST_EXACT. */
 enum { XP_LCL_INTERP_LINEAR = 0, XP_LCL_INTERP_LOG = 1 };
 
 /* error codes */
@@ -139,6 +144,12 @@ int xp_init(int device);
    xarray_parcel_amd.adiabat_tables or loaded from its cache file). */
 int xp_set_tables(const xp_tables *tables);
 int xp_tables_loaded(void);
+
+/* The adiabat-family table of XP_MOIST_FAMILY, [n_lnp][n_label] doubles (no reference counterpart: the reference's
+   tables are the XP_MOIST_TABLE ones).  Read it back (out may be NULL to query the shape) or replace it, e.g. with
+   the oracle's independently built copy in the parity tests. */
+int xp_family_table(double *out, int64_t *n_lnp, int64_t *n_label);
+int xp_set_family_table(const double *table, int64_t n_lnp, int64_t n_label);
 
 /* pf.py:1394-1475 cape_cin and its three drivers: surface_based_cape_cin (pf.py:1477),
    most_unstable_cape_cin (pf.py:1557), mixed_layer_cape_cin (pf.py:1651); with `profile` non-NULL

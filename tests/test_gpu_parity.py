@@ -281,3 +281,51 @@ def test_strided_device_views_through_the_raw_abi():
     o32 = L.Opts(1, 1, 1, 0, 0, L.XP_F32, (C.c_int32 * 2)(0, 0))
     assert lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o32),
                            C.byref(so), None, None) == -1                 # XP_E_ARG: fp32 arithmetic not implemented
+
+
+# ---- adiabat-family exact mode (XP_MOIST_FAMILY) --------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def family_tables():
+    """The product builds its own table at xp_init; it must equal the oracle's independently built one to rounding.
+    The parity tests then run on the oracle's copy so that both sides interpolate identical numbers."""
+    own = xa.family_table()
+    ref = co.family_table()
+    assert own.shape == ref.shape and float(np.max(np.abs(own - ref))) < 1e-9
+    xa.set_family_table(ref)
+    yield ref
+    xa.set_family_table(own)
+
+
+@pytest.mark.parametrize('name', sorted(k for k in kr.RECIPES if k != 'test_insert_level'))
+def test_kat_family_mode(name, family_tables):
+    xa.set_moist_lapse('family')
+    try:
+        kr.run(name, xa, loosen=RK4_LOOSEN.get(name))
+    finally:
+        xa.set_moist_lapse('exact')
+
+
+@pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_family_columns_vs_oracle(parcel, mode, dtype, family_tables):
+    kw = MODES[mode]
+    p, t, td = synth.columns(nlev=48, ncol=12000, seed=41 + mode, nan_fraction=0.08, dtype=dtype)
+    got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist='family', **kw)
+    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='family', **kw)
+    _compare(got, ref, dtype, 1e-6)
+
+
+def test_family_falls_back_to_rk4_outside_the_table(family_tables):
+    """Columns reaching above 32 hPa, or with labels outside 216..314 K, are redone by the RK4 kernel: identical to a
+    plain exact-mode call there, identical to the oracle's family mode everywhere."""
+    p, t, td = synth.columns(nlev=40, ncol=3000, seed=5, dtype=np.float64)
+    p[-1, ::3] = 20.0                                     # top level above the table
+    t[:, 1::7] -= 55.0; td[:, 1::7] -= 55.0              # very cold columns: label below the table
+    got = xa.cape_cin_columns(p, t, td, moist='family', want_profile=True)
+    ref = co.cape_cin_grid(p, t, td, moist='family', want_profile=True)
+    _compare(got, ref, np.float64, 1e-6)
+    rk = xa.cape_cin_columns(p, t, td, moist='exact')
+    assert np.array_equal(got['cape'][::3], rk['cape'][::3])
+    ok = ~np.isnan(ref['profile']['temperature'])
+    assert np.max(np.abs(got['profile']['temperature'][ok] - ref['profile']['temperature'][ok])) <= 1e-8

@@ -13,12 +13,12 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), 'include', 'xparcel.h')
 XP_F32, XP_F64 = 0, 1
 XP_MEM_HOST, XP_MEM_DEVICE = 0, 1
 PARCEL = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
-MOIST = {'exact': 0, 'table': 1}
+MOIST = {'exact': 0, 'table': 1, 'family': 2}
 LCL_INTERP = {'linear': 0, 'log': 1}
 ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE = 1, 2, 4
 
 # every symbol include/xparcel.h declares
-SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
+SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
            'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_last_error')
 

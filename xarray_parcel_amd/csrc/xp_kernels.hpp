@@ -39,6 +39,9 @@ struct CapeArgs {
     int vtc, log_interp, pos_neg, post_zero, table_mode;
     Tables tb;
     const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
+    const double *fam_tab;                // adiabat-family table [FAM_NX][FAM_NS] (family mode)
+    int32_t *flags;                       // family mode: 1 = column must be redone by the RK4 kernel
+    int only_flagged;                     // RK4 fix-up pass: process flagged columns only
     ScalarsOut s;
     ProfileOut prof;
 };
@@ -129,12 +132,24 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // its LCL; decided with a ballot) carries the full logic: dry or moist parcel, bracketing levels for the
 // environment at the LCL, emission of the LCL node.  Phase B (every lane above its LCL) is the steady state
 // and only advances the moist adiabat, so the LCL machinery costs nothing for most of the column.
-template <typename T, int PMODE, bool PROFILE, bool TABLE>
-__global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
+// MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
+// flagged and redone by a MODE 0 launch with only_flagged set).
+template <typename T, int PMODE, bool PROFILE, int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+    constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
-    const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.ncol) return;
+    if (a.only_flagged) {                                                  // fix-up pass: most blocks have nothing to do
+        int need = (c < a.ncol) ? a.flags[c] : 0;
+        if (!__syncthreads_or(need)) return;
+        const double *es0 = stage_es_table(a.es_tab, s_es);
+        (void)es0;
+        if (!need) return;
+    } else {
+        stage_es_table(a.es_tab, s_es);
+        if (c >= a.ncol) return;
+    }
+    const double *es = s_es;
 
     Parcel pc;
     if (PMODE == PM_SURFACE) {
@@ -164,6 +179,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         st(s.lfc_p, s.f64, c, qnan()); st(s.lfc_t, s.f64, c, qnan()); st(s.el_p, s.f64, c, qnan()); st(s.el_t, s.f64, c, qnan());
         sti(s.lfc_idx, c, -1); sti(s.el_idx, c, -1); sti(s.status, c, status); sti(s.parcel_idx, c, pc.idx);
         st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
+        if (FAMILY) a.flags[c] = 0;
         return;
     }
 
@@ -182,7 +198,10 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
 
     Scan sc; sc.init(l.p, a.pos_neg != 0);
-    Moist m; m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
+    Moist m;
+    Family fam;
+    if (FAMILY) fam.start(a.fam_tab, x_lcl, l.t, dt_dlnp_e(l.p, l.t, es_tab(es, l.t)));
+    else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int64_t jout = 0;                                                      // profile row
     auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
@@ -227,8 +246,8 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
     auto moist_node = [&](double P, double X, double T_, double Td_) __attribute__((always_inline)) {
         // one wave-uniform range test per level instead of one per e_s evaluation
         bool fast = __builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull;
-        double tp = m.at(P, X, a.tb, true);                                // NaN pressure -> NaN
-        double w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;                  // pf.py:760
+        double tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);           // NaN pressure -> NaN
+        double w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;      // pf.py:760
         double tvp = need_w ? virt(tp, w) : tp;
         double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P, fast)) : T_;   // pf.py:839-843
         emit(P, X, tp, tvp, T_, tve, Td_, false);
@@ -246,8 +265,8 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
             tp = pc.t * fexp(KAPPA * (X - x0));
             w = w_parcel;
         } else {
-            tp = m.at(P, X, a.tb);
-            w = need_w ? mix_of_e(TABLE ? es_tab(es, tp) : m.e, P) : 0.0;
+            tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb);
+            w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;
         }
         double tvp = need_w ? virt(tp, w) : tp;
         double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
         // evaluate them in its operation order with library math.
         bool on_lcl = need_w && (P == l.p);
         if (__builtin_amdgcn_ballot_w64(on_lcl) != 0ull && on_lcl) {
-            double ta = m.at(P, X, a.tb);
+            double ta = FAMILY ? l.t : m.at(P, X, a.tb);
             asm volatile("" : "+v"(ta));
             double ea = es_ref(ta);
             tvp = tp * (1.0 + VT_EPS * (EPS * ea / (P - ea)));
@@ -293,6 +312,7 @@ __global__ __launch_bounds__(256) void k_cape_cin(CapeArgs a) {
 
     Scan::Result r = sc.finish(lcl_t_arg, a.post_zero != 0);
     status |= r.status;
+    if (FAMILY) a.flags[c] = fam.bad ? 1 : 0;
     st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
     st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t);
     st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);

@@ -36,6 +36,8 @@ struct State {
     xp::Tables tb{};
     void *tb_index = nullptr, *tb_adiabats = nullptr;
     double *es_tab = nullptr;   // device copy of the e_s(T) polynomial table
+    double *fam_tab = nullptr;  // device copy of the adiabat-family table
+    std::vector<double> fam_host;
 } g;
 
 size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
@@ -116,6 +118,35 @@ struct Stager {
     }
 };
 
+// adiabat-family table (xp::Family; specification restated independently in oracle/family.py): for every label psi_j
+// march MetPy's pseudo-adiabat from 1000 hPa to every ln p node by classical RK4, 8 substeps per interval
+double fam_dt_dlnp(double x, double t) {
+    double p = std::exp(x), e = 6.112 * std::exp(17.67 * (t - 273.15) / (t - 29.65)), pe = p - e;
+    double num = xp::RD * t * pe + xp::LV * xp::EPS * e;
+    double den = xp::CP_D * xp::RD * t * t * pe + xp::LV * xp::LV * xp::EPS * xp::EPS * e;
+    return xp::RD * t * t * num / den;
+}
+void build_family_table(double *tab) {
+    const int i_up = (int)std::floor((xp::FAM_X1000 - xp::FAM_XLO) / xp::FAM_DX);
+    for (int j = 0; j < xp::FAM_NS; ++j)
+        for (int dir = -1; dir <= 1; dir += 2) {
+            double t = xp::FAM_SLO + xp::FAM_DS * j, x = xp::FAM_X1000;
+            for (int i = (dir < 0 ? i_up : i_up + 1); i >= 0 && i < xp::FAM_NX; i += dir) {
+                double x1 = xp::FAM_XLO + xp::FAM_DX * i, h = (x1 - x) / xp::FAM_SUB;
+                for (int s = 0; s < xp::FAM_SUB; ++s) {
+                    double k1 = fam_dt_dlnp(x, t);
+                    double k2 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
+                    double k3 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
+                    double k4 = fam_dt_dlnp(x + h, t + h * k3);
+                    t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+                    x = x + h;
+                }
+                x = x1;
+                tab[(size_t)i * xp::FAM_NS + j] = t;
+            }
+        }
+}
+
 int check_view(const xp_view *v, const char *name) {
     if (!v || !v->data) return fail(XP_E_ARG, "%s: null view", name);
     if (v->dtype != XP_F32 && v->dtype != XP_F64) return fail(XP_E_ARG, "%s: dtype must be XP_F32 or XP_F64", name);
@@ -162,14 +193,19 @@ int stage_scalars(Stager &st, xp_scalars_out *s, int64_t ncol, xp::ScalarsOut *o
     return rc;
 }
 
-template <typename T, int PM, bool TABLE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
-    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, TABLE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, TABLE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+template <typename T, int PM, int MODE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
+    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
 }
 template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     if (a.ncol == 0) return;
-    if (a.table_mode) launch_cape_t<T, PM, true>(a, profile, s);
-    else launch_cape_t<T, PM, false>(a, profile, s);
+    if (a.table_mode) launch_cape_t<T, PM, 1>(a, profile, s);
+    else if (a.flags) {                                      // family mode: fast pass, then RK4 for the flagged columns
+        launch_cape_t<T, PM, 2>(a, profile, s);
+        xp::CapeArgs b = a;
+        b.only_flagged = 1;
+        launch_cape_t<T, PM, 0>(b, profile, s);
+    } else launch_cape_t<T, PM, 0>(a, profile, s);
 }
 template <typename T> void launch_cape_pm(const xp::CapeArgs &a, int pm, bool profile, hipStream_t s) {
     switch (pm) {
@@ -192,6 +228,7 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     a->nlev = p->nlev; a->ncol = p->ncol;
     a->depth = parcel->depth;
     a->es_tab = g.es_tab;
+    a->fam_tab = g.fam_tab;
     if (parcel->mode == XP_PARCEL_EXPLICIT) {
         if (!parcel->pressure || !parcel->temperature || !parcel->dewpoint) return fail(XP_E_ARG, "explicit parcel: null arrays");
         size_t b = (size_t)p->ncol * esize(p->dtype);
@@ -201,7 +238,8 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     if (o) {
         if (o->lcl_interp != XP_LCL_INTERP_LINEAR && o->lcl_interp != XP_LCL_INTERP_LOG)
             return fail(XP_E_INTERP, "interpolator must be linear or log");
-        if (o->moist_mode != XP_MOIST_EXACT && o->moist_mode != XP_MOIST_TABLE) return fail(XP_E_ARG, "bad moist_mode");
+        if (o->moist_mode != XP_MOIST_EXACT && o->moist_mode != XP_MOIST_TABLE && o->moist_mode != XP_MOIST_FAMILY)
+            return fail(XP_E_ARG, "bad moist_mode");
         if (o->compute != XP_F64) return fail(XP_E_ARG, "xp_opts.compute: only XP_F64 arithmetic is implemented");
         a->vtc = o->virtual_temperature_correction; a->log_interp = o->lcl_interp == XP_LCL_INTERP_LOG;
         a->pos_neg = o->pos_cape_neg_cin; a->post_zero = o->post_zero_cin; a->table_mode = o->moist_mode == XP_MOIST_TABLE;
@@ -241,6 +279,12 @@ int xp_init(int device) {
         HIP_TRY(hipMalloc((void **)&g.es_tab, sizeof(double) * xp::LDS_TAB));
         HIP_TRY(hipMemcpy(g.es_tab, tab.data(), sizeof(double) * xp::LDS_TAB, hipMemcpyHostToDevice));
     }
+    if (g.init && g.device != device && g.fam_tab) { (void)hipFree(g.fam_tab); g.fam_tab = nullptr; }
+    if (!g.fam_tab) {
+        if (g.fam_host.empty()) { g.fam_host.resize((size_t)xp::FAM_NX * xp::FAM_NS); build_family_table(g.fam_host.data()); }
+        HIP_TRY(hipMalloc((void **)&g.fam_tab, sizeof(double) * g.fam_host.size()));
+        HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
+    }
     g.device = device;
     g.init = true;
     return XP_OK;
@@ -266,6 +310,24 @@ int xp_set_tables(const xp_tables *t) {
 }
 int xp_tables_loaded(void) { return g.tables ? 1 : 0; }
 
+int xp_family_table(double *out, int64_t *n_lnp, int64_t *n_label) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n_lnp) *n_lnp = xp::FAM_NX;
+    if (n_label) *n_label = xp::FAM_NS;
+    if (out) memcpy(out, g.fam_host.data(), sizeof(double) * g.fam_host.size());
+    return XP_OK;
+}
+int xp_set_family_table(const double *tab, int64_t n_lnp, int64_t n_label) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!tab || n_lnp != xp::FAM_NX || n_label != xp::FAM_NS) return fail(XP_E_ARG, "xp_set_family_table: wrong shape");
+    std::lock_guard<std::mutex> lk(g.mu);
+    memcpy(g.fam_host.data(), tab, sizeof(double) * g.fam_host.size());
+    HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
+    return XP_OK;
+}
+
 int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel, const xp_opts *o,
                 xp_scalars_out *scalars, xp_profile_out *profile, void *stream) {
     int rc = ensure_init();
@@ -288,8 +350,14 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
         a.prof.nlev_out = profile->nlev_out; a.prof.ls = profile->lev_stride; a.prof.cs = profile->col_stride;
         a.prof.f64 = profile->dtype == XP_F64;
     }
+    void *flags = nullptr;
+    if (o && o->moist_mode == XP_MOIST_FAMILY && a.ncol > 0) {
+        HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)a.ncol, st.s));   // stream-ordered scratch: which columns need RK4
+        a.flags = (int32_t *)flags;
+    }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
     else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
+    if (flags) HIP_TRY(hipFreeAsync(flags, st.s));
     return st.finish();
 }
 
@@ -388,7 +456,7 @@ int xp_moist_lapse(const xp_view *p, const void *pt, const void *pp, int32_t moi
         (rc = st.out(out, fb, p->mem, &od))) return rc;
     ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
     xp::Tables tb = g.tb;
-    int tm = moist_mode == XP_MOIST_TABLE;
+    int tm = moist_mode == XP_MOIST_TABLE;   /* XP_MOIST_FAMILY is served by the RK4 stepper in the component kernels */
     if (p->ncol) {
         if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_moist_lapse<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, (const double *)g.es_tab, ov);
         else hipLaunchKernelGGL((xp::k_moist_lapse<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dt, dp, tm, tb, (const double *)g.es_tab, ov);
@@ -414,7 +482,7 @@ int xp_parcel_profile(const xp_view *p, const void *pp, const void *pt, const vo
     ot.data = d1; ot.ls = p->lev_stride; ot.cs = p->col_stride;
     otv.data = d2; otv.ls = p->lev_stride; otv.cs = p->col_stride;
     xp::Tables tb = g.tb;
-    int tm = moist_mode == XP_MOIST_TABLE;
+    int tm = moist_mode == XP_MOIST_TABLE;   /* XP_MOIST_FAMILY is served by the RK4 stepper in the component kernels */
     if (p->ncol) {
         if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_parcel_profile<double>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, (const double *)g.es_tab, ot, otv, d3, d4, d5);
         else hipLaunchKernelGGL((xp::k_parcel_profile<float>), dim3(blocks(p->ncol)), dim3(256), 0, st.s, pv, p->nlev, p->ncol, dpp, dpt, dptd, tm, tb, (const double *)g.es_tab, ot, otv, d3, d4, d5);
@@ -482,7 +550,7 @@ int xp_wet_bulb_temperature(const xp_view *p, const xp_view *t, const xp_view *t
         (rc = st.out(out, (size_t)p->nlev * (size_t)p->ncol * esize(p->dtype), p->mem, &od))) return rc;
     ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
     xp::Tables tb = g.tb;
-    int tm = moist_mode == XP_MOIST_TABLE;
+    int tm = moist_mode == XP_MOIST_TABLE;   /* XP_MOIST_FAMILY is served by the RK4 stepper in the component kernels */
     int64_t n = p->nlev * p->ncol;
     if (n) {
         if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_wet_bulb<double>), dim3(blocks(n)), dim3(256), 0, st.s, pv, tv, tdv, p->nlev, p->ncol, tm, tb, (const double *)g.es_tab, ov);

@@ -135,8 +135,8 @@ _DEFAULT = {'moist': 'exact'}
 
 
 def set_moist_lapse(mode):
-    """'exact' (RK4 integration of MetPy's ODE) or 'table' (the reference's lookup tables; needs
-    adiabat_tables.load_moist_adiabat_lookups())."""
+    """'exact' (RK4 integration of MetPy's ODE), 'family' (the same ODE from the adiabat-family table, faster) or
+    'table' (the reference's lookup tables; needs adiabat_tables.load_moist_adiabat_lookups())."""
     assert mode in L.MOIST
     _DEFAULT['moist'] = mode
 
@@ -411,3 +411,19 @@ def lifted_index(profile):
     env = interp_level(profile['pressure'], profile['environment_temperature'], 500.0, log=True)
     par = interp_level(profile['pressure'], profile['temperature'], 500.0, log=True)
     return env - par
+
+
+def family_table():
+    """The adiabat-family table of moist='family' as a (n_lnp, n_label) float64 array (xp_family_table)."""
+    lib = L.init()
+    n1, n2 = C.c_int64(), C.c_int64()
+    L.check(lib.xp_family_table(None, C.byref(n1), C.byref(n2)))
+    out = np.empty((n1.value, n2.value), dtype=np.float64)
+    L.check(lib.xp_family_table(out.ctypes.data_as(C.c_void_p), None, None))
+    return out
+
+
+def set_family_table(table):
+    """Replace the adiabat-family table (xp_set_family_table)."""
+    t = np.ascontiguousarray(table, dtype=np.float64)
+    L.check(L.init().xp_set_family_table(t.ctypes.data_as(C.c_void_p), C.c_int64(t.shape[0]), C.c_int64(t.shape[1])))
