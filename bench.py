@@ -80,6 +80,16 @@ def main():
     ap.add_argument('--nx', type=int, default=NX)
     a = ap.parse_args()
 
+    # the in-tree library normally travels with the snapshot; if it is missing, local rank 0 builds it and the others wait
+    from xarray_parcel_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        if int(os.environ.get('LOCAL_RANK', '0')) == 0:
+            _lib.build()
+        else:
+            while not os.path.exists(_lib.LIB_PATH):
+                time.sleep(1.0)
+            time.sleep(2.0)
+
     import torch
     import torch.distributed as dist
     from xarray_parcel_amd import numpy_api as xa

@@ -10,3 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _native_builds():
+    """Make sure the in-tree native pieces exist (no-ops when they are up to date): the HIP library is cross-compiled
+    by hipcc, the C oracle by gcc.  Nothing here needs a GPU."""
+    from xarray_parcel_amd import _lib
+    _lib.build()
+    from oracle import c_oracle
+    c_oracle.build()
+    yield
