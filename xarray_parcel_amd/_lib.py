@@ -83,10 +83,12 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', LIB_PATH, os.path.join(SRC_DIR, 'xparcel.hip')]
+    tmp = LIB_PATH + '.tmp%d' % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', tmp, os.path.join(SRC_DIR, 'xparcel.hip')]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)           # atomic: a concurrent loader never sees a half-written library
     return LIB_PATH
 
 

@@ -182,6 +182,17 @@ XP_DEV const double *stage_es_table(const double *g, double *lds) {
     return lds;
 }
 
+// ln(theta_e): same ordering as theta_e (monotone), without the two pow and the exp -- what the most-unstable search
+// actually needs (argmax over the layer, pf.py:127-128); ln from the LDS table
+XP_DEV double ln_theta_e(const double *tb, double p, double t, double td) {
+    double e = es_tab(tb, td), r = mix_of_e(e, p);
+    double lt = log_tab(tb, t), ltd = log_tab(tb, td);
+    double tl = 56.0 + frcp(frcp(td - 56.0) + (lt - ltd) * (1.0 / 800.0));
+    double ltl = log_tab(tb, tl);
+    return lt + KAPPA * (6.907755278982137 - log_tab(tb, p - e)) + 0.28 * r * (lt - ltl) +
+           r * (1.0 + 0.448 * r) * (fdiv(3036.0, tl) - 1.78);
+}
+
 // ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
 // Same iteration and stop rule as MetPy / the oracle, in the fast fp64 forms above: the result agrees with theirs to
 // ~1e-13 relative, not to the last bit.  The LCL decides on which side of the condensation level every model level

@@ -53,19 +53,21 @@ struct Parcel { double p, t, td; int64_t first; int idx; bool prepend; };
 // most_unstable_parcel (pf.py:102-135 with get_layer pf.py:63-100 and bound_pressure pf.py:208-227):
 // highest theta-e in the lowest `depth` hPa, first maximum wins; the layer top is the level closest to
 // p_bottom - depth (ties -> higher pressure).
-template <typename T> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c) {
+template <typename T> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
+    // one-level software prefetch: the loop is otherwise a chain of dependent HBM round trips
+    double np_ = ld<T>(a.p, 0, c), nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = ld<T>(a.p, k, c);
+        double p = np_, t = nt_, td = ntd_;
+        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         if (isnan_(p)) continue;
         if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
         double d = fabs(p - bound);
         bool below = p < bound;
         if (below && !(d < dmin)) break;                  // the level above the bound is at least as close
         if (!(d >= dmin)) dmin = d;
-        double t = ld<T>(a.t, k, c), td = ld<T>(a.td, k, c);
-        double e = theta_e(p, t, td);
+        double e = ln_theta_e(es, p, t, td);               // argmax of theta_e = argmax of its logarithm
         if (!isnan_(e) && !(e <= best)) { best = e; r.p = p; r.t = t; r.td = td; r.first = k; r.idx = (int)k; }
         if (below) break;
     }
@@ -90,8 +92,10 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
     double pp = qnan(), thp = qnan(), wp = qnan();        // previous row of the layer
     double pb = qnan(), thb = qnan(), wb = qnan();        // last row with a valid pressure >= top
     bool closed = false;
+    double np_ = p_start, nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);      // one-level software prefetch
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = ld<T>(a.p, k, c), t = ld<T>(a.t, k, c), td = ld<T>(a.td, k, c);
+        double p = np_, t = nt_, td = ntd_;
+        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - a.depth; }
         if (!isnan_(p) && p < top) {
             // insert the interpolated top row, close the integral; the profile continues from this level
@@ -135,7 +139,8 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
 template <typename T, int PMODE, bool PROFILE, int MODE>
-__global__ __launch_bounds__(256, (MODE == 2 ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+    // 3 waves/SIMD = 168 VGPRs: SB gets there unforced (164); the MU / ML / explicit variants sit at 170-180 and are held to it
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 1)) void k_cape_cin(CapeArgs 
         pc.p = ld1<T>(a.ex_p, c); pc.t = ld1<T>(a.ex_t, c); pc.td = ld1<T>(a.ex_td, c);
         pc.first = 0; pc.idx = -1; pc.prepend = false;
     } else if (PMODE == PM_MU) {
-        pc = select_mu<T>(a, c);
+        pc = select_mu<T>(a, c, es);
     } else {
         pc = select_ml<T>(a, c);
     }
@@ -287,8 +292,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 1)) void k_cape_cin(CapeArgs 
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
+    int64_t k = pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
     // software-prefetched level loop
-    int64_t k = pc.first;
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
     for (; k < a.nlev; ++k) {                                              // phase A
@@ -321,9 +326,11 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 3 : 1)) void k_cape_cin(CapeArgs 
 
 // parcels only (most_unstable_parcel pf.py:102, mixed_parcel pf.py:229)
 template <typename T, int PMODE> __global__ __launch_bounds__(256) void k_select_parcel(CapeArgs a) {
+    __shared__ double s_es[LDS_TAB];
+    const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
-    Parcel pc = (PMODE == PM_MU) ? select_mu<T>(a, c) : select_ml<T>(a, c);
+    Parcel pc = (PMODE == PM_MU) ? select_mu<T>(a, c, es) : select_ml<T>(a, c);
     st(a.s.par_p, a.s.f64, c, pc.p); st(a.s.par_t, a.s.f64, c, pc.t); st(a.s.par_td, a.s.f64, c, pc.td);
     sti(a.s.parcel_idx, c, pc.idx);
 }
