@@ -116,8 +116,12 @@ __device__ __attribute__((noinline)) double log_slow(double x) { return log(x); 
 // coefficient-major so that the lanes of a wavefront -- whose temperatures fall in different intervals --
 // hit different LDS banks.  Out-of-range or NaN temperatures take the formula.
 constexpr double ES_T_LO = 120.0;
-constexpr int ES_N = 210, ES_DEG = 7, ES_TAB = (ES_DEG + 1) * ES_N;
-constexpr int LOG_N = 64, LOG_TAB = 2 * LOG_N;      // ln table: 1/c_i and ln c_i for 64 mantissa intervals
+// Row stride 257 doubles: (a) more than the 255 x 8 B reach of ds_read2_b64 and not a multiple of 64, so every
+// coefficient is its own ds_read_b64 (2 LDS cycles, banks (a/4) mod 64) instead of half a ds_read2_b64 (8 cycles per
+// pair, banks mod 32: measured 48 % of all LDS cycles were bank conflicts with the merged reads); (b) odd, so that
+// row c is rotated by c banks against row 0.
+constexpr int ES_N = 210, ES_DEG = 7, ES_STRIDE = 257, ES_TAB = (ES_DEG + 1) * ES_STRIDE;
+constexpr int LOG_N = 64, LOG_TAB = 2 * ES_STRIDE;  // ln table: 1/c_i and ln c_i for 64 mantissa intervals, same row stride
 constexpr int LDS_TAB = ES_TAB + LOG_TAB;
 // `all_in_range` is a wave-uniform promise by the caller that every lane's t lies inside the table (the per-level
 // code tests T, Td and the parcel temperature once per level with margins, see in_table()); without it the
@@ -132,13 +136,13 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     }
     double r = u - ((double)i + 0.5);
     const double *c = tb + i;
-    double p = c[7 * ES_N];
-    p = __builtin_fma(p, r, c[6 * ES_N]);
-    p = __builtin_fma(p, r, c[5 * ES_N]);
-    p = __builtin_fma(p, r, c[4 * ES_N]);
-    p = __builtin_fma(p, r, c[3 * ES_N]);
-    p = __builtin_fma(p, r, c[2 * ES_N]);
-    p = __builtin_fma(p, r, c[1 * ES_N]);
+    double p = c[7 * ES_STRIDE];
+    p = __builtin_fma(p, r, c[6 * ES_STRIDE]);
+    p = __builtin_fma(p, r, c[5 * ES_STRIDE]);
+    p = __builtin_fma(p, r, c[4 * ES_STRIDE]);
+    p = __builtin_fma(p, r, c[3 * ES_STRIDE]);
+    p = __builtin_fma(p, r, c[2 * ES_STRIDE]);
+    p = __builtin_fma(p, r, c[1 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[0]);
     if (!all_in_range) {
         // behind a wave-uniform test and an asm barrier so that the compiler cannot fold the slow path into the
@@ -170,7 +174,7 @@ XP_DEV double log_tab(const double *tb, double x) {
     q = __builtin_fma(q, r, 1.0 / 3.0);
     q = __builtin_fma(q, r, -0.5);
     q = __builtin_fma(q, r, 1.0);
-    return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lt[LOG_N + i]));
+    return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lt[ES_STRIDE + i]));
 }
 XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p, bool fast = false) {
     return EPS * fdiv(es_tab(tb, td, fast), p - es_tab(tb, t, fast));

@@ -68,14 +68,14 @@ void build_es_table(double *out) {
                 for (int j = col; j <= n; ++j) A[r][j] -= f * A[col][j];
             }
         }
-        for (int j = 0; j < n; ++j) out[j * xp::ES_N + i] = (double)(A[j][n] / A[j][j]);
+        for (int j = 0; j < n; ++j) out[j * xp::ES_STRIDE + i] = (double)(A[j][n] / A[j][j]);
     }
     // ln table for xp::log_tab: mantissa interval i of [0.5, 1) has centre c_i = (i + 64.5) / 128
     double *lt = out + xp::ES_TAB;
     for (int i = 0; i < xp::LOG_N; ++i) {
         LD c = ((LD)i + 64.5L) / 128.0L;
         lt[i] = (double)(1.0L / c);
-        lt[xp::LOG_N + i] = (double)logl(c);
+        lt[xp::ES_STRIDE + i] = (double)logl(c);
     }
 }
 
@@ -193,9 +193,15 @@ int stage_scalars(Stager &st, xp_scalars_out *s, int64_t ncol, xp::ScalarsOut *o
     return rc;
 }
 
+int cape_block() {
+    static int b = [] { const char *e = getenv("XP_CAPE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    return b;
+}
 template <typename T, int PM, int MODE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
-    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE>), dim3(blocks(a.ncol)), dim3(256), 0, s, a);
+    const int b = cape_block();
+    dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
+    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE>), gr, bl, 0, s, a);
+    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE>), gr, bl, 0, s, a);
 }
 template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     if (a.ncol == 0) return;
