@@ -485,7 +485,7 @@ struct Family {
 // index, so "the lowest pressure where both temperatures exist" (pf.py:1143-1147) is the LAST such node.
 struct Scan {
     // configuration
-    double p_lcl;
+    double p_lcl, x_lcl;   // LCL pressure and its logarithm (the X of the LCL node)
     bool pos_neg;
     // previous node
     double Xp, yp, parp;
@@ -493,17 +493,18 @@ struct Scan {
     bool use_all;          // env[0] != par[0] (pf.py:1117-1120)
     // prefix sums and snapshots
     double cape, cin, cape_lcl, cin_lcl, cape_lfc, cin_lfc, cape_el;
-    // crossings
-    double lfc_p, lfc_t, el_p, el_t;
+    // crossings, kept as ln p: pressures decrease along the scan, so "bottom LFC" / "top EL" order the same in ln p,
+    // and the two exponentials a column actually needs are taken once, in finish()
+    double lfc_x, lfc_t, el_x, el_t;
     int lfc_idx, el_idx;
     bool any_inc, pos_parcel, env_any;
     double top_par, top_env, min_p;
 
-    XP_DEV void init(double p_lcl_, bool pos_neg_) {
-        p_lcl = p_lcl_; pos_neg = pos_neg_;
+    XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_) {
+        p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_;
         Xp = yp = parp = qnan(); j = 0; use_all = true;
         cape = cin = cape_lcl = cin_lcl = cape_lfc = cin_lfc = cape_el = 0.0;
-        lfc_p = lfc_t = el_p = el_t = qnan(); lfc_idx = el_idx = -1;
+        lfc_x = lfc_t = el_x = el_t = qnan(); lfc_idx = el_idx = -1;
         any_inc = pos_parcel = env_any = false;
         top_par = top_env = min_p = qnan();
     }
@@ -511,45 +512,60 @@ struct Scan {
         if (pos_neg) { cape += fmax(a, 0.0); cin += fmin(a, 0.0); }      // maxNum/minNum drop a NaN operand
         else { double b = isnan_(a) ? 0.0 : a; cape += b; cin += b; }
     }
-    // first node, or an interval whose end points differ in sign / are NaN (pf.py:1019-1022)
-    XP_DEV void special(double X, double par, double env, double y, double a_reg) {
-        if (j == 0) { use_all = (env != par); return; }
-        int i = j - 1;
-        // Some lane of a wavefront has a crossing in most iterations, so this path is not that rare per wave: fast
-        // division / exp / ln here, except for the zero-width interval of a duplicated pressure (IEEE 0/0 must give
-        // NaN as in NumPy) and for a crossing within 1e-9 of the LCL pressure, whose "p* < p_lcl" tie is broken with
-        // the library exp/log exactly as on the CPU.
-        double xs, frac;
-        bool dup = (X == Xp);
-        if (__builtin_amdgcn_ballot_w64(dup) != 0ull && dup) {
-            xs = (y * Xp - yp * X) / (y - yp);                              // pf.py:1046
-            frac = (xs - Xp) / (X - Xp);
-        } else {
-            xs = fdiv(y * Xp - yp * X, y - yp);
-            frac = fdiv(xs - Xp, X - Xp);
-        }
-        double zy = frac * (y - yp) + yp;                                   // zero crossing of y (pf.py:1225-1231)
-        if (isnan_(zy)) { add(a_reg); return; }                             // no valid zero: plain trapezoid (NaN -> skipped)
-        double ps = fexp(xs), zlog = xs;                                    // ln(exp(xs)) (pf.py:1237) = xs to 1 ulp
-        bool near_lcl = fabs(ps - p_lcl) <= 1e-9 * p_lcl;
+    // pressure of a crossing stored as ln p; one within 2e-9 of the LCL takes the library exp, like the CPU
+    XP_DEV double crossing_pressure(double xs) const {
+        double ps = fexp(xs);
+        bool near_lcl = fabs(xs - x_lcl) <= 2e-9;
         if (__builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
             double q = xs;
             asm volatile("" : "+v"(q));
             ps = exp_slow(q);
+        }
+        return ps;
+    }
+    // first node, or an interval whose end points differ in sign / are NaN (pf.py:1019-1022)
+    XP_DEV void special(double X, double par, double env, double y, double a_reg) {
+        if (j == 0) { use_all = (env != par); return; }
+        int i = j - 1;
+        // Some lane of a wavefront has a crossing in most iterations when neighbouring columns are unrelated (the
+        // bench's are), so this path is not rare per wave: one fast reciprocal, no exp / ln.  Exceptions, behind
+        // ballots: the zero-width interval of a duplicated pressure (IEEE 0/0 must give NaN as in NumPy), and a
+        // crossing within 2e-9 (in ln p) of the LCL, whose "p* < p_lcl" tie is broken with the library exp / log
+        // exactly as on the CPU.
+        double d = y - yp, xs, frac;
+        bool dup = (X == Xp);
+        if (__builtin_amdgcn_ballot_w64(dup) != 0ull && dup) {
+            xs = (y * Xp - yp * X) / d;                                     // pf.py:1046
+            frac = (xs - Xp) / (X - Xp);
+        } else {
+            double r = frcp(d);
+            xs = (y * Xp - yp * X) * r;
+            frac = -yp * r;                                                 // = (xs - Xp) / (X - Xp)
+        }
+        double zy = frac * d + yp;                                          // zero crossing of y (pf.py:1225-1231)
+        if (isnan_(zy)) { add(a_reg); return; }                             // no valid zero: plain trapezoid (NaN -> skipped)
+        double zlog = xs;                                                   // ln(exp(xs)) (pf.py:1237) = xs to 1 ulp
+        bool above = xs < x_lcl;                                            // p* < p_lcl
+        bool near_lcl = fabs(xs - x_lcl) <= 2e-9;
+        if (__builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
+            double q = xs;
+            asm volatile("" : "+v"(q));
+            double ps = exp_slow(q);
             zlog = log_slow(ps);
+            above = ps < p_lcl;
         }
         add((yp * 0.5) * fabs(Xp - zlog));                                  // lower triangle (pf.py:1246-1273)
         double ys = frac * (par - parp) + parp;                             // pf.py:1050
-        if (!isnan_(ps)) {
+        if (!isnan_(xs)) {
             bool in_sel = use_all || i >= 1;
             if (y > 0.0 && in_sel) {                                        // increasing crossing
                 any_inc = true;
-                if (ps < p_lcl && !(ps <= lfc_p)) {                         // bottom LFC above the LCL (pf.py:1127-1132)
-                    lfc_p = ps; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
+                if (above && !(xs <= lfc_x)) {                              // bottom LFC above the LCL (pf.py:1127-1132)
+                    lfc_x = xs; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
                 }
             }
-            if (y < 0.0 && i >= 1 && !(ps >= el_p)) {                       // top EL (pf.py:1136-1138)
-                el_p = ps; el_t = ys; el_idx = i; cape_el = cape;
+            if (y < 0.0 && i >= 1 && !(xs >= el_x)) {                       // top EL (pf.py:1136-1138)
+                el_x = xs; el_t = ys; el_idx = i; cape_el = cape;
             }
         }
         add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
@@ -575,6 +591,7 @@ struct Scan {
     XP_DEV Result finish(double lcl_t, bool post_zero) {
         Result r;
         r.status = 0;
+        double lfc_p = crossing_pressure(lfc_x), el_p = crossing_pressure(el_x);
         // EL exists only if the parcel ends colder than the environment and the EL is above the LCL
         bool el_ok = (top_par <= top_env) && (el_p < p_lcl);                    // pf.py:1151-1155
         if (!el_ok) { el_p = qnan(); el_t = qnan(); el_idx = -1; }

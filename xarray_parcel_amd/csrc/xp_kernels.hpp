@@ -139,7 +139,7 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
 template <typename T, int PMODE, bool PROFILE, int MODE>
-__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
     // 3 waves/SIMD = 168 VGPRs: SB gets there unforced (164); the MU / ML / explicit variants sit at 170-180 and are held to it
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE) ? 3 : 1)) 
     const double x_lcl = log(l.p);
     const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
 
-    Scan sc; sc.init(l.p, a.pos_neg != 0);
+    Scan sc; sc.init(l.p, x_lcl, a.pos_neg != 0);
     Moist m;
     Family fam;
     if (FAMILY) fam.start(a.fam_tab, x_lcl, l.t, dt_dlnp_e(l.p, l.t, es_tab(es, l.t)));
@@ -449,7 +449,7 @@ void k_lfc_el(View pv, View parv, View envv, int64_t nlev, int64_t ncol, const v
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     double lp = ld1<T>(lcl_p, c), lt = ld1<T>(lcl_t, c);
-    Scan sc; sc.init(lp, true);
+    Scan sc; sc.init(lp, log(lp), true);
     for (int64_t k = 0; k < nlev; ++k) {
         double P = ld<T>(pv, k, c);
         sc.node(P, flog(P), ld<T>(parv, k, c), ld<T>(envv, k, c), false);
