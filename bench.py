@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--moist', default='exact', choices=['exact', 'family'],
                     help='exact = RK4 stepper; family = same ODE from the adiabat-family table (xparcel.h)')
+    ap.add_argument('--humidity', default='dewpoint', choices=['dewpoint', 'specific'],
+                    help="'specific': feed specific humidity and convert on load (XP_HUM_SPECIFIC); not the headline")
     ap.add_argument('--nlev', type=int, default=NLEV)
     ap.add_argument('--ny', type=int, default=NY)
     ap.add_argument('--nx', type=int, default=NX)
@@ -117,6 +119,11 @@ def main():
     tdt = torch.float64 if a.dtype == 'f64' else torch.float32
     ncol = a.ny * a.nx
     p, t, td = synth.columns_torch(a.nlev, ncol, dev, seed=20250719, dtype=tdt, col_offset=rank * ncol)
+    if a.humidity == 'specific':                                   # q of air with the synthetic dewpoint (exact inversion)
+        e = 6.112 * torch.exp(17.67 * (td - 273.15) / (td - 29.65))
+        w = 0.6219569100577033 * e / (p - e)
+        td = (w / (1.0 + w)).to(tdt)
+        del e, w
     want = ('cape', 'cin')
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered = [torch.empty((world, 2, ncol), dtype=tdt, device=cdev) for _ in range(2)] if (world > 1 and rank == 0) else None
@@ -127,7 +134,7 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = xa.cape_cin_columns(p, t, td, want=want, moist=a.moist)
+        r = xa.cape_cin_columns(p, t, td, want=want, moist=a.moist, humidity=a.humidity)
         e1.record()
         if timed:
             kernel_ms.append((e0, e1))

@@ -50,6 +50,10 @@ enum { XP_PARCEL_SURFACE = 0, XP_PARCEL_MOST_UNSTABLE = 1, XP_PARCEL_MIXED_LAYER
    XP_MOIST_TABLE emulates the reference's lookup tables (pf.py:525-607) against tables given
    to xp_set_tables(). */
 enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1, XP_MOIST_FAMILY = 2 };
+/* XP_HUM_SPECIFIC: the moisture view holds specific humidity [kg/kg] (what the reference's data files provide) and is
+   converted to dewpoint on load with the xp_dewpoint_from_specific_humidity chain (parcel_test.py:262-266), saving the
+   separate pass and the (nlev, ncol) dewpoint array.  Explicit parcels (xp_parcel.dewpoint) stay dewpoints. */
+enum { XP_HUM_DEWPOINT = 0, XP_HUM_SPECIFIC = 1 };
 /* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a table of its solutions T(ln p ; theta_w) built at
    xp_init and interpolated 6 x 6 (within 1.4e-6 K of the ODE, the RK4 stepper of XP_MOIST_EXACT within 2e-5 K); about
    a third fewer fp64 instructions per level.  Columns whose label or levels leave the table (theta_w outside
@@ -98,7 +102,8 @@ typedef struct {
     int32_t post_zero_cin;                  /* default 0 (pf.py:1293) */
     int32_t moist_mode;                     /* XP_MOIST_* */
     int32_t compute;                        /* arithmetic type: XP_F64 (the only one implemented; XP_F32 is rejected with XP_E_ARG) */
-    int32_t reserved[2];
+    int32_t humidity;                       /* XP_HUM_*: what the `dewpoint` view of xp_cape_cin holds */
+    int32_t reserved;
 } xp_opts;
 
 /* Per-column outputs; every pointer is nullable (not written when NULL).  Floating outputs have
@@ -209,6 +214,18 @@ int xp_wet_bulb_temperature(const xp_view *pressure, const xp_view *temperature,
    Used by lifted_index (pf.py:1722), deep_convective_index (pf.py:1830), isobar_temperature (pf.py:2193). */
 int xp_interp_level(const xp_view *coords, const xp_view *variable, const void *at, int32_t at_is_scalar,
                     int32_t log_coords, void *out, void *stream);
+
+/* metpy.calc.dewpoint_from_specific_humidity in its MetPy 1.4.1 form, the front step of the reference's harness and
+   products (parcel_test.py:262-266, pf.py:1889-1894, 1969-1974): w = q/(1-q), RH = w / w_s(p, T),
+   Td = dewpoint(RH e_s(T)) [K].  Element-wise; out has the layout of `pressure`.  No reference fixture pins this
+   function: parity unpinned beyond the oracle's restatement. */
+int xp_dewpoint_from_specific_humidity(const xp_view *pressure, const xp_view *temperature,
+                                       const xp_view *specific_humidity, void *out, void *stream);
+
+/* pf.py:2137-2158 freezing_level_height (and melting_level_height, pf.py:2160-2191, on the wet-bulb field): the
+   smallest x over all intersections (find_intersections pf.py:992-1064, linear in x) of the profile a(x) with the
+   constant `value`; NaN where the profile never crosses it.  One value per column. */
+int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *out, void *stream);
 
 const char *xp_last_error(void);
 

@@ -597,4 +597,50 @@ def wet_bulb_temperature(pressure, temperature, dewpt, moist=None):
     return out
 
 
+def wet_bulb_temperature_fast(temperature, dewpt):
+    """pf.py:364-387 ("1/3 rule")."""
+    return _f(temperature) - (1 / 3) * (_f(temperature) - _f(dewpt))
+
+
+def freezing_level_height(temperature, height):
+    """pf.py:2137-2158: lowest x among all intersections of the temperature profile with 273.15 K."""
+    t = _f(temperature)
+    ix = find_intersections(_f(height), t, np.full(t.shape, 273.15))['all_intersect_x']
+    return _nmin(ix)
+
+
+def melting_level_height(pressure, temperature, dewpt, height, fast=True, moist=None):
+    """pf.py:2160-2191."""
+    wb = wet_bulb_temperature_fast(temperature, dewpt) if fast else \
+        wet_bulb_temperature(pressure, temperature, dewpt, moist=moist)
+    return freezing_level_height(wb, height), wb
+
+
+def isobar_temperature(pressure, temperature, isobar):
+    """pf.py:2193-2214."""
+    return log_interp(temperature, pressure, isobar)
+
+
+def lapse_rate(pressure, temperature, height, from_pressure=700, to_pressure=500):
+    """pf.py:2102-2135 [K/km]."""
+    t0 = log_interp(temperature, pressure, from_pressure)
+    t1 = log_interp(temperature, pressure, to_pressure)
+    z0 = log_interp(height, pressure, from_pressure) / 1000
+    z1 = log_interp(height, pressure, to_pressure) / 1000
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return (t1 - t0) / (z1 - z0)
+
+
+def deep_convective_index(pressure, temperature, dewpt, li):
+    """pf.py:1830-1870 (Kunz 2009) [deg C]."""
+    dat = log_interp({'temperature': temperature, 'dewpoint': dewpt}, pressure, 850.0)
+    return (dat['temperature'] - 273.15) + (dat['dewpoint'] - 273.15) - li
+
+
+def surface_cape_vector(pressure, temperature, specific_humidity, **kwargs):
+    """parcel_test.py:250-274: q -> dewpoint (MetPy 1.4.1 chain), then surface-based CAPE / CIN."""
+    td = th.dewpoint_from_specific_humidity(_f(pressure), _f(temperature), _f(specific_humidity))
+    return surface_based_cape_cin(pressure, temperature, td, **kwargs)
+
+
 warnings.filterwarnings('ignore', message='Mean of empty slice')

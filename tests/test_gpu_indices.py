@@ -1,0 +1,161 @@
+"""GPU parity tests for the SURVEY 8(f) rows built on the hot path: the q -> dewpoint front step (stand-alone and fused
+into xp_cape_cin), the single-level indices (pf.py:1830-1870, 2102-2214) and the harness counterpart (parcel_test.py).
+
+Oracle: oracle/thermo.py + oracle/parcel_oracle.py (NumPy restatement, one column at a time).  None of these functions
+has a KAT in the reference's unit tests except lifted_index, so for them parity is against the restatement only
+("parity unpinned" for dewpoint_from_specific_humidity).
+Tolerances: element-wise fp64 formulas 1e-10 K; interpolated / intersected values 1e-9 relative; CAPE / CIN through the
+fused path 1e-6 J/kg with bit-exact level indices.
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import parcel_oracle as po
+from oracle import thermo as th
+from tests.test_gpu_parity import _compare
+from xarray_parcel_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def xa():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the GPU'
+    from xarray_parcel_amd import numpy_api
+    return numpy_api
+
+
+def _specific_humidity(p, td):
+    """Specific humidity of air with dewpoint td (exact thermodynamics; MetPy 1.4.1's chain maps it back to within
+    ~0.1 K of td, see tests/test_oracle_indices.py)."""
+    e = th.saturation_vapor_pressure(td)
+    w = th.EPSILON * e / (p - e)
+    return w / (1.0 + w)
+
+
+def _heights(p):
+    return 44330.8 * (1.0 - (p / 1013.25) ** 0.190263)       # standard-atmosphere altitude [m], monotone in p
+
+
+def test_dewpoint_from_specific_humidity(xa):
+    p, t, td = synth.columns(nlev=30, ncol=500, seed=5, nan_fraction=0.05, dtype=np.float64)
+    q = _specific_humidity(p, td)
+    q[3, ::17] = 0.0                                                # log(0): NaN in MetPy's formula chain
+    q[4, ::19] = -1e-4
+    got = xa.dewpoint_from_specific_humidity(p, t, q)
+    with np.errstate(all='ignore'):
+        ref = th.dewpoint_from_specific_humidity(p, t, q)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(got[ok] - ref[ok])) <= 1e-10
+    g32 = xa.dewpoint_from_specific_humidity(p.astype(np.float32), t.astype(np.float32), q.astype(np.float32))
+    assert g32.dtype == np.float32
+    with np.errstate(all='ignore'):
+        r32 = th.dewpoint_from_specific_humidity(p.astype(np.float32).astype(np.float64), t.astype(np.float32).astype(np.float64),
+                                                 q.astype(np.float32).astype(np.float64))
+    ok = ~np.isnan(r32)
+    assert np.array_equal(np.isnan(g32), ~ok)
+    assert np.max(np.abs(g32[ok] - r32[ok])) <= 3e-5
+
+
+@pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_fused_specific_humidity_input(xa, parcel, dtype):
+    """XP_HUM_SPECIFIC: the moisture view holds q and is converted on load; oracle = convert, then the same driver."""
+    p, t, td = synth.columns(nlev=48, ncol=8000, seed=23, nan_fraction=0.08, dtype=np.float64)
+    q = _specific_humidity(p, td).astype(dtype)
+    p, t = p.astype(dtype), t.astype(dtype)
+    with np.errstate(all='ignore'):
+        td_ref = th.dewpoint_from_specific_humidity(p.astype(np.float64), t.astype(np.float64), q.astype(np.float64))
+    got = xa.cape_cin_columns(p, t, q, parcel=parcel, humidity='specific')
+    ref = co.cape_cin_grid(p.astype(np.float64), t.astype(np.float64), td_ref, parcel=parcel, moist='rk4')
+    _compare(got, ref, dtype, 1e-6)
+    # and the two-step route of the reference (parcel_test.py:262-271) gives the same answer as the fused one
+    two = xa.cape_cin_columns(p, t, xa.dewpoint_from_specific_humidity(p, t, q), parcel=parcel)
+    if dtype == np.float64:
+        same = np.asarray(two['lfc_index']) == np.asarray(got['lfc_index'])
+        assert same.mean() > 0.999
+        a, b = np.asarray(two['cape'])[same], np.asarray(got['cape'])[same]
+        assert np.nanmax(np.abs(a - b)) <= 1e-6
+
+
+def test_single_level_indices_vs_oracle(xa):
+    p, t, td = synth.columns(nlev=40, ncol=300, seed=31, nan_fraction=0.06, dtype=np.float64)
+    z = _heights(p)
+    # make some columns cross 273.15 K several times / never / exactly on a level
+    t2 = t.copy()
+    t2[5:9, ::7] += 12.0 * np.sin(np.arange(4))[:, None]
+    t2[:, 1::11] = np.minimum(t2[:, 1::11], 270.0)                   # never reaches freezing: NaN
+    t2[6, 2::13] = 273.15                                           # a level exactly on the isotherm
+    flh = xa.freezing_level_height(t2, z)
+    mlh, wb = xa.melting_level_height(p, t2, td, z)
+    lr = xa.lapse_rate(p, t, z)
+    t500 = xa.isobar_temperature(p, t, 500.0)
+    res = xa.cape_cin_columns(p, t, td, parcel='mixed_layer', want_profile=True)
+    li = xa.lifted_index(res['profile'])
+    dci = xa.deep_convective_index(p, t, td, li)
+
+    def close(a, b, what, c, tol=1e-9):
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= tol * max(1.0, abs(b)), (what, c, a, b)
+
+    with np.errstate(all='ignore'):
+        for c in range(p.shape[1]):
+            close(flh[c], po.freezing_level_height(t2[:, c], z[:, c]), 'flh', c)
+            r_mlh, r_wb = po.melting_level_height(p[:, c], t2[:, c], td[:, c], z[:, c])
+            close(mlh[c], r_mlh, 'mlh', c)
+            close(lr[c], po.lapse_rate(p[:, c], t[:, c], z[:, c]), 'lapse', c)
+            close(t500[c], po.isobar_temperature(p[:, c], t[:, c], 500.0), 't500', c)
+            r_li = po.lifted_index({k: res['profile'][k][:, c] for k in ('pressure', 'temperature', 'environment_temperature')})
+            close(li[c], r_li, 'li', c)
+            close(dci[c], po.deep_convective_index(p[:, c], t[:, c], td[:, c], r_li), 'dci', c, tol=1e-8)
+    cold = np.setdiff1d(np.arange(1, p.shape[1], 11), np.arange(2, p.shape[1], 13))
+    assert np.isnan(flh[cold]).all() and np.isfinite(flh[::7]).any()
+    # exact wet bulb leg of melting_level_height (fast=False) runs the Normand kernel
+    mlh2, wb2 = xa.melting_level_height(p[:, :16], t2[:, :16], td[:, :16], z[:, :16], fast=False)
+    with np.errstate(all='ignore'):
+        for c in range(0, 16, 5):
+            po.set_moist_lapse('rk4')
+            try:
+                r, _ = po.melting_level_height(p[:, c], t2[:, c], td[:, c], z[:, c], fast=False)
+            finally:
+                po.set_moist_lapse('ode')
+            close(mlh2[c], r, 'mlh exact', c, tol=1e-7)
+
+
+def test_xarray_mirrors_and_harness(xa):
+    """parcel_functions / parcel_test mirrors: names, attrs and values (against the array API they wrap)."""
+    from xarray_parcel_amd import parcel_functions as pf
+    from xarray_parcel_amd import parcel_test as pt
+    from xarray_parcel_amd._xr import DataArray, Dataset
+    nlev, ny, nx = 30, 9, 11
+    p, t, td = synth.columns(nlev=nlev, ncol=ny * nx, seed=41, dtype=np.float64)
+    q = _specific_humidity(p, td)
+    dims = ('model_level_number', 'latitude', 'longitude')
+    coords = {'model_level_number': np.arange(nlev), 'latitude': np.linspace(-30, -20, ny), 'longitude': np.linspace(140, 150, nx)}
+    mk = lambda a, n: DataArray(a.reshape(nlev, ny, nx), dims=dims, coords=coords, name=n)
+    P, T, TD, Q, Z = mk(p, 'pressure'), mk(t, 'temperature'), mk(td, 'dewpoint'), mk(q, 'specific_humidity'), mk(_heights(p), 'height')
+    flh = pf.freezing_level_height(temperature=T, height=Z)
+    assert flh.name == 'freezing_level' and flh.attrs['units'] == 'm' and flh.dims == ('latitude', 'longitude')
+    assert np.allclose(flh.values.ravel(), xa.freezing_level_height(t, _heights(p)), equal_nan=True)
+    mlh, wb = pf.melting_level_height(pressure=P, temperature=T, dewpoint=TD, height=Z)
+    assert mlh.name == 'melting_level' and wb.attrs['description'] == 'Estimated using 1/3 method.'
+    lr = pf.lapse_rate(pressure=P, temperature=T, height=Z)
+    assert lr.attrs['description'] == '700-500 hPa lapse rate' and lr.attrs['units'] == 'K km$^{-1}$'
+    t500 = pf.isobar_temperature(pressure=P, temperature=T, isobar=500)
+    assert t500.attrs == {'description': 'Temperature at 500 hPa.', 'long_name': 'Isobar temperature', 'units': 'K'}
+    cc, prof, _ = pf.mixed_layer_cape_cin(pressure=P, temperature=T, dewpoint=TD, prefix='mixed_100')
+    li = pf.lifted_index(profile=prof, prefix='mixed_100', description='x')
+    dci = pf.deep_convective_index(pressure=P, temperature=T, dewpoint=TD, lifted_index=li['mixed_100_lifted_index'], prefix='mixed_100')
+    assert 'mixed_100_dci' in dci and dci['mixed_100_dci'].attrs['units'] == 'C'
+    tdq = pf.dewpoint_from_specific_humidity(pressure=P, temperature=T, specific_humidity=Q)
+    assert tdq.dims == dims and np.nanmax(np.abs(tdq.values.reshape(nlev, -1) - th.dewpoint_from_specific_humidity(p, t, q))) < 1e-9
+    # harness: fused and two-step routes agree; benchmark_cape returns one time per sub-grid
+    dat = Dataset({'pressure': P, 'temperature': T, 'specific_humidity': Q})
+    a, b = pt.surface_cape_vector(dat), pt.surface_cape_vector(dat, fused=False)
+    assert np.nanmax(np.abs(a['cape'].values - b['cape'].values)) <= 1e-6
+    ref = co.cape_cin_grid(p, t, th.dewpoint_from_specific_humidity(p, t, q), moist='rk4')
+    assert np.nanmax(np.abs(a['cape'].values.ravel() - ref['cape'])) <= 1e-6
+    bench = pt.benchmark_cape(dat, points=[2, 4, 9])
+    assert list(bench['xr_load'].coords['pts']) == [4, 16, 81] and np.all(bench['device'].values > 0)

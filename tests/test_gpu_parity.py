@@ -272,13 +272,13 @@ def test_strided_device_views_through_the_raw_abi():
     so.dtype, so.mem = L.XP_F64, L.XP_MEM_DEVICE
     so.cape, so.cin, so.lfc_index = cape.data_ptr(), cin.data_ptr(), idx.data_ptr()
     pc = L.Parcel(L.PARCEL['surface'], 0, 0.0, None, None, None)
-    o = L.Opts(1, 1, 1, 0, 0, L.XP_F64, (C.c_int32 * 2)(0, 0))
+    o = L.Opts(1, 1, 1, 0, 0, L.XP_F64, 0, 0)
     L.check(lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o),
                             C.byref(so), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert np.array_equal(cape.cpu().numpy(), dense['cape']) and np.array_equal(cin.cpu().numpy(), dense['cin'])
     assert np.array_equal(idx.cpu().numpy(), dense['lfc_index'])
-    o32 = L.Opts(1, 1, 1, 0, 0, L.XP_F32, (C.c_int32 * 2)(0, 0))
+    o32 = L.Opts(1, 1, 1, 0, 0, L.XP_F32, 0, 0)
     assert lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o32),
                            C.byref(so), None, None) == -1                 # XP_E_ARG: fp32 arithmetic not implemented
 

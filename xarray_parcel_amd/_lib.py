@@ -15,12 +15,14 @@ XP_MEM_HOST, XP_MEM_DEVICE = 0, 1
 PARCEL = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
 MOIST = {'exact': 0, 'table': 1, 'family': 2}
 LCL_INTERP = {'linear': 0, 'log': 1}
+HUMIDITY = {'dewpoint': 0, 'specific': 1}
 ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE = 1, 2, 4
 
 # every symbol include/xparcel.h declares
 SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
-           'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_last_error')
+           'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_dewpoint_from_specific_humidity',
+           'xp_crossing_level', 'xp_last_error')
 
 
 class View(C.Structure):
@@ -36,7 +38,7 @@ class Parcel(C.Structure):
 class Opts(C.Structure):
     _fields_ = [('virtual_temperature_correction', C.c_int32), ('lcl_interp', C.c_int32),
                 ('pos_cape_neg_cin', C.c_int32), ('post_zero_cin', C.c_int32), ('moist_mode', C.c_int32),
-                ('compute', C.c_int32), ('reserved', C.c_int32 * 2)]
+                ('compute', C.c_int32), ('humidity', C.c_int32), ('reserved', C.c_int32)]
 
 
 SCALAR_F = ('cape', 'cin', 'lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature', 'lfc_pressure',

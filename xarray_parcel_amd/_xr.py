@@ -36,10 +36,12 @@ except Exception:
             return DataArray(self.values.transpose(order), dims=dims, coords=self.coords, attrs=self.attrs,
                              name=self.name)
 
-        def isel(self, indexers):
+        def isel(self, indexers=None, **kw):
             out = self
-            for d, i in indexers.items():
+            for d, i in {**(indexers or {}), **kw}.items():
                 ax = out.dims.index(d)
+                if isinstance(i, slice):
+                    i = np.arange(out.shape[ax])[i]
                 vals = np.take(out.values, i, axis=ax)
                 coords = {k: (np.take(v, i, axis=0) if k == d else v) for k, v in out.coords.items()}
                 if np.ndim(i) == 0:
@@ -52,6 +54,20 @@ except Exception:
 
         def __getitem__(self, i):
             return self.isel({self.dims[0]: i})
+
+        def _binary(self, other, op):
+            o = other.values if isinstance(other, DataArray) else other
+            if isinstance(other, DataArray):
+                assert other.dims == self.dims, 'the stand-in does not broadcast by dimension name'
+            return DataArray(op(self.values, o), dims=self.dims, coords=self.coords, attrs={}, name=self.name)
+
+        def __add__(self, o): return self._binary(o, np.add)
+        def __radd__(self, o): return self._binary(o, np.add)
+        def __sub__(self, o): return self._binary(o, np.subtract)
+        def __rsub__(self, o): return self._binary(o, lambda a, b: b - a)
+        def __mul__(self, o): return self._binary(o, np.multiply)
+        def __rmul__(self, o): return self._binary(o, np.multiply)
+        def __truediv__(self, o): return self._binary(o, np.divide)
 
         def __array__(self, dtype=None, copy=None):
             return self.values if dtype is None else self.values.astype(dtype)

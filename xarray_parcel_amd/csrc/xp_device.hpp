@@ -197,6 +197,15 @@ XP_DEV double ln_theta_e(const double *tb, double p, double t, double td) {
            r * (1.0 + 0.448 * r) * (fdiv(3036.0, tl) - 1.78);
 }
 
+// the same chain on the per-level path of xp_cape_cin (XP_HUM_SPECIFIC): LDS tables and fast division;
+// RH e_s(T) = w (p - e_s(T)) / eps.  q <= 0 or q >= 1 has no dewpoint (MetPy: log of a non-positive number -> NaN).
+XP_DEV double dewpoint_from_q_tab(const double *tb, double p, double t, double q) {
+    double e = fdiv(q, 1.0 - q) * (p - es_tab(tb, t)) * (1.0 / EPS);
+    double v = log_tab(tb, e * (1.0 / 6.112));
+    double td = 273.15 + 243.5 * fdiv(v, 17.67 - v);
+    return (e > 0.0) ? td : qnan();
+}
+
 // ---- LCL: metpy.calc.lcl as a per-column Steffensen iteration (pf.py:609-682) -------------------
 // Same iteration and stop rule as MetPy / the oracle, in the fast fp64 forms above: the result agrees with theirs to
 // ~1e-13 relative, not to the last bit.  The LCL decides on which side of the condensation level every model level
@@ -205,6 +214,14 @@ XP_DEV double ln_theta_e(const double *tb, double p, double t, double td) {
 // test_profile_with_lcl_in_levels puts a level exactly on it.  The level loop therefore treats a level within 1e-9
 // (relative) of p_lcl as lying ON the LCL (LCL_SNAP), which is what bitwise equality selects in the reference.
 XP_DEV double es_ref(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
+// metpy.calc.dewpoint_from_specific_humidity, MetPy 1.4.1 chain (parcel_test.py:262-266, pf.py:1889):
+// w = q/(1-q); RH = w / w_s(p, T); Td = dewpoint(RH * e_s(T)) -- library exp/log, reference operation order
+XP_DEV double dewpoint_from_q(double p, double t, double q) {
+    double w = q / (1.0 - q);
+    double est = es_ref(t);
+    double rh = w / (EPS * est / (p - est));
+    return dewpoint_of_e(rh * est);
+}
 XP_DEV double dewpoint_fast(double e) { double v = flog(e * (1.0 / 6.112)); return 273.15 + 243.5 * fdiv(v, 17.67 - v); }
 XP_DEV double lcl_iter(double p, double p0, double w, double t) {
     double td = dewpoint_fast(p * fdiv(w, EPS + w));

@@ -37,6 +37,7 @@ struct CapeArgs {
     const void *ex_p, *ex_t, *ex_td;      // explicit parcel
     double depth;
     int vtc, log_interp, pos_neg, post_zero, table_mode;
+    int hum;                              // 1: the td view holds specific humidity (host side: picks the HUM instantiation)
     Tables tb;
     const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
     const double *fam_tab;                // adiabat-family table [FAM_NX][FAM_NS] (family mode)
@@ -48,18 +49,24 @@ struct CapeArgs {
 
 enum { PM_SURFACE = 0, PM_MU = 1, PM_ML = 2, PM_EXPLICIT = 3 };
 
+// moisture input of one level -> dewpoint [K] (XP_HUM_SPECIFIC converts, see xparcel.h); a compile-time switch: as a
+// run-time flag it cost the dewpoint path 5 VGPRs and 3 %
+template <bool HUM> XP_DEV double as_dewpoint(const double *es, double p, double t, double m) {
+    return HUM ? dewpoint_from_q_tab(es, p, t, m) : m;
+}
+
 struct Parcel { double p, t, td; int64_t first; int idx; bool prepend; };
 
 // most_unstable_parcel (pf.py:102-135 with get_layer pf.py:63-100 and bound_pressure pf.py:208-227):
 // highest theta-e in the lowest `depth` hPa, first maximum wins; the layer top is the level closest to
 // p_bottom - depth (ties -> higher pressure).
-template <typename T> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
+template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
     // one-level software prefetch: the loop is otherwise a chain of dependent HBM round trips
     double np_ = ld<T>(a.p, 0, c), nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = np_, t = nt_, td = ntd_;
+        double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         if (isnan_(p)) continue;
         if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
@@ -84,7 +91,7 @@ XP_DEV double interp_rule(double xb, double xa, double at, double cb, double ca)
     double res = xb + (xa - xb) * fdiv(at - cb, ca - cb);
     return (xb == xa) ? xb : res;
 }
-template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
+template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c, const double *es) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = true;
     double p_start = ld<T>(a.p, 0, c);
     double bottom = qnan(), top = qnan();
@@ -94,7 +101,7 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
     bool closed = false;
     double np_ = p_start, nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);      // one-level software prefetch
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = np_, t = nt_, td = ntd_;
+        double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - a.depth; }
         if (!isnan_(p) && p < top) {
@@ -138,8 +145,9 @@ template <typename T> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c) {
 // and only advances the moist adiabat, so the LCL machinery costs nothing for most of the column.
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
-template <typename T, int PMODE, bool PROFILE, int MODE>
-__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+// HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
+template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
+__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE || HUM) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
     // 3 waves/SIMD = 168 VGPRs: SB gets there unforced (164); the MU / ML / explicit variants sit at 170-180 and are held to it
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
@@ -158,15 +166,15 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE)
 
     Parcel pc;
     if (PMODE == PM_SURFACE) {
-        pc.p = ld<T>(a.p, 0, c); pc.t = ld<T>(a.t, 0, c); pc.td = ld<T>(a.td, 0, c);
+        pc.p = ld<T>(a.p, 0, c); pc.t = ld<T>(a.t, 0, c); pc.td = as_dewpoint<HUM>(es, pc.p, pc.t, ld<T>(a.td, 0, c));
         pc.first = 0; pc.idx = 0; pc.prepend = false;
     } else if (PMODE == PM_EXPLICIT) {
         pc.p = ld1<T>(a.ex_p, c); pc.t = ld1<T>(a.ex_t, c); pc.td = ld1<T>(a.ex_td, c);
         pc.first = 0; pc.idx = -1; pc.prepend = false;
     } else if (PMODE == PM_MU) {
-        pc = select_mu<T>(a, c, es);
+        pc = select_mu<T, HUM>(a, c, es);
     } else {
-        pc = select_ml<T>(a, c);
+        pc = select_ml<T, HUM>(a, c, es);
     }
 
     const bool need_w = a.vtc || PROFILE;
@@ -298,12 +306,12 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE)
     if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
     for (; k < a.nlev; ++k) {                                              // phase A
         if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
-        double P = np_, T_ = nt_, Td_ = ntd_;
+        double P = np_, T_ = nt_, Td_ = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         source(P, T_, Td_);
     }
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
-        double P = np_, T_ = nt_, Td_ = ntd_;
+        double P = np_, T_ = nt_, Td_ = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         moist_node(P, log_tab(es, P), T_, Td_);
     }
@@ -330,7 +338,7 @@ template <typename T, int PMODE> __global__ __launch_bounds__(256) void k_select
     const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
-    Parcel pc = (PMODE == PM_MU) ? select_mu<T>(a, c, es) : select_ml<T>(a, c);
+    Parcel pc = (PMODE == PM_MU) ? select_mu<T, false>(a, c, es) : select_ml<T, false>(a, c, es);
     st(a.s.par_p, a.s.f64, c, pc.p); st(a.s.par_t, a.s.f64, c, pc.t); st(a.s.par_td, a.s.f64, c, pc.td);
     sti(a.s.parcel_idx, c, pc.idx);
 }
@@ -555,6 +563,37 @@ void k_interp_level(View cv, View xv, int64_t nlev, int64_t ncol, const void *at
     double xb = nb ? sb / (double)nb : qnan(), xa = na ? sa / (double)na : qnan();
     double res = xb + (xa - xb) * ((at - cb) / (ca - cb));
     st(out, sizeof(T) == 8, c, (xb == xa) ? xb : res);                     // pf.py:1802-1806
+}
+
+// dewpoint_from_specific_humidity (MetPy 1.4.1, parcel_test.py:262-266): one thread per element
+template <typename T> __global__ __launch_bounds__(256)
+void k_dewpoint_from_q(View pv, View tv, View qv, int64_t nlev, int64_t ncol, OutView out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nlev * ncol) return;
+    int64_t k = e / ncol, c = e - k * ncol;
+    st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, dewpoint_from_q(ld<T>(pv, k, c), ld<T>(tv, k, c), ld<T>(qv, k, c)));
+}
+
+// freezing_level_height (pf.py:2137-2158): the smallest x among ALL intersections (find_intersections pf.py:992-1064,
+// linear x) of a(x) with the constant `value`, NaN when there is none.  An interval counts when sign(a - value)
+// changes or is NaN at either end (pf.py:1019-1022); its intersection is NaN unless all four numbers are finite.
+template <typename T> __global__ __launch_bounds__(256)
+void k_crossing_level(View xv, View av, int64_t nlev, int64_t ncol, double value, void *out) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double best = qnan(), x0 = qnan(), d0 = qnan();
+    for (int64_t k = 0; k < nlev; ++k) {
+        double x1 = ld<T>(xv, k, c), d1 = ld<T>(av, k, c) - value;
+        if (k > 0) {
+            double s0 = (double)((d0 > 0.0) - (d0 < 0.0)), s1 = (double)((d1 > 0.0) - (d1 < 0.0));
+            if (isnan_(d0) || isnan_(d1) || s0 != s1) {
+                double xi = (d1 * x0 - d0 * x1) / (d1 - d0);               // pf.py:1046
+                if (!isnan_(xi) && !(xi >= best)) best = xi;
+            }
+        }
+        x0 = x1; d0 = d1;
+    }
+    st(out, sizeof(T) == 8, c, best);
 }
 
 }  // namespace xp

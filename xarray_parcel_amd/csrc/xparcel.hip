@@ -200,8 +200,13 @@ int cape_block() {
 template <typename T, int PM, int MODE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     const int b = cape_block();
     dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
-    if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE>), gr, bl, 0, s, a);
-    else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE>), gr, bl, 0, s, a);
+    if (a.hum) {
+        if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE, true>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE, true>), gr, bl, 0, s, a);
+    } else {
+        if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE, false>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE, false>), gr, bl, 0, s, a);
+    }
 }
 template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     if (a.ncol == 0) return;
@@ -248,9 +253,11 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
             return fail(XP_E_ARG, "bad moist_mode");
         if (o->compute != XP_F64) return fail(XP_E_ARG, "xp_opts.compute: only XP_F64 arithmetic is implemented");
         a->vtc = o->virtual_temperature_correction; a->log_interp = o->lcl_interp == XP_LCL_INTERP_LOG;
+        if (o->humidity != XP_HUM_DEWPOINT && o->humidity != XP_HUM_SPECIFIC) return fail(XP_E_ARG, "bad xp_opts.humidity");
         a->pos_neg = o->pos_cape_neg_cin; a->post_zero = o->post_zero_cin; a->table_mode = o->moist_mode == XP_MOIST_TABLE;
+        a->hum = o->humidity == XP_HUM_SPECIFIC;
     } else {
-        a->vtc = 1; a->log_interp = 1; a->pos_neg = 1; a->post_zero = 0; a->table_mode = 0;
+        a->vtc = 1; a->log_interp = 1; a->pos_neg = 1; a->post_zero = 0; a->table_mode = 0; a->hum = 0;
     }
     if (a->table_mode) {
         if (!g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
@@ -582,6 +589,43 @@ int xp_interp_level(const xp_view *coords, const xp_view *x, const void *at, int
     if (coords->ncol) {
         if (coords->dtype == XP_F64) hipLaunchKernelGGL((xp::k_interp_level<double>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
         else hipLaunchKernelGGL((xp::k_interp_level<float>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
+    }
+    return st.finish();
+}
+
+int xp_dewpoint_from_specific_humidity(const xp_view *p, const xp_view *t, const xp_view *q, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(q, "specific_humidity")) ||
+        (rc = same_shape(p, t, "pressure/temperature")) || (rc = same_shape(p, q, "pressure/specific_humidity"))) return rc;
+    if (!out) return fail(XP_E_ARG, "xp_dewpoint_from_specific_humidity: null output");
+    Stager st(stream);
+    xp::View pv, tv, qv; xp::OutView ov;
+    void *od;
+    if ((rc = stage_view(st, p, &pv)) || (rc = stage_view(st, t, &tv)) || (rc = stage_view(st, q, &qv)) ||
+        (rc = st.out(out, (size_t)p->nlev * (size_t)p->ncol * esize(p->dtype), p->mem, &od))) return rc;
+    ov.data = od; ov.ls = p->lev_stride; ov.cs = p->col_stride;
+    int64_t n = p->nlev * p->ncol;
+    if (n) {
+        if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_dewpoint_from_q<double>), dim3(blocks(n)), dim3(256), 0, st.s, pv, tv, qv, p->nlev, p->ncol, ov);
+        else hipLaunchKernelGGL((xp::k_dewpoint_from_q<float>), dim3(blocks(n)), dim3(256), 0, st.s, pv, tv, qv, p->nlev, p->ncol, ov);
+    }
+    return st.finish();
+}
+
+int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(x, "x")) || (rc = check_view(a, "a")) || (rc = same_shape(x, a, "x/a"))) return rc;
+    if (!out) return fail(XP_E_ARG, "xp_crossing_level: null output");
+    Stager st(stream);
+    xp::View xv, av;
+    void *od;
+    if ((rc = stage_view(st, x, &xv)) || (rc = stage_view(st, a, &av)) ||
+        (rc = st.out(out, (size_t)x->ncol * esize(x->dtype), x->mem, &od))) return rc;
+    if (x->ncol) {
+        if (x->dtype == XP_F64) hipLaunchKernelGGL((xp::k_crossing_level<double>), dim3(blocks(x->ncol)), dim3(256), 0, st.s, xv, av, x->nlev, x->ncol, value, od);
+        else hipLaunchKernelGGL((xp::k_crossing_level<float>), dim3(blocks(x->ncol)), dim3(256), 0, st.s, xv, av, x->nlev, x->ncol, value, od);
     }
     return st.finish();
 }

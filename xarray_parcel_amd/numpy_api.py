@@ -124,11 +124,12 @@ def _per_col(x, ncol, dt, dev, like):
 
 
 def _opts(virtual_temperature_correction=True, lcl_interp='log', pos_cape_neg_cin=True, post_zero_cin=False,
-          moist='exact'):
+          moist='exact', humidity='dewpoint'):
     if lcl_interp not in L.LCL_INTERP:
         raise AssertionError('interpolator must be linear or log')          # pf.py:878
+    assert humidity in L.HUMIDITY, "humidity must be 'dewpoint' or 'specific'"
     return L.Opts(int(bool(virtual_temperature_correction)), L.LCL_INTERP[lcl_interp], int(bool(pos_cape_neg_cin)),
-                  int(bool(post_zero_cin)), L.MOIST[moist], L.XP_F64, (C.c_int32 * 2)(0, 0))
+                  int(bool(post_zero_cin)), L.MOIST[moist], L.XP_F64, L.HUMIDITY[humidity], 0)
 
 
 _DEFAULT = {'moist': 'exact'}
@@ -143,7 +144,9 @@ def set_moist_lapse(mode):
 
 def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=None, parcel_values=None,
                      want_profile=False, want=None, moist=None, **kwargs):
-    """pf.py:1394-1475 with the three drivers.  Returns a dict of per-column arrays (and 'profile')."""
+    """pf.py:1394-1475 with the three drivers.  Returns a dict of per-column arrays (and 'profile').
+    humidity='specific' (keyword): `dewpoint` holds specific humidity [kg/kg] and is converted on load
+    (parcel_test.py:262-266 fused into the pass)."""
     (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
     assert p.shape == t.shape == td.shape, 'pressure, temperature, dewpoint must share a shape'
     nlev, ncol, hshape = _vert_shape(p)
@@ -404,6 +407,69 @@ def interp_level(coords, variable, at, log=False):
     L.check(lib.xp_interp_level(C.byref(_view(cds, nlev, ncol)), C.byref(_view(x, nlev, ncol)), C.c_void_p(ah.ptr),
                                 C.c_int32(int(scalar)), C.c_int32(int(log)), C.c_void_p(optr), _stream(dev)))
     return out.reshape(hshape)
+
+
+def dewpoint_from_specific_humidity(pressure, temperature, specific_humidity):
+    """metpy.calc.dewpoint_from_specific_humidity, MetPy 1.4.1 chain (parcel_test.py:262-266, pf.py:1889), K."""
+    (p, t, q), dt, dev = _common(pressure, temperature, specific_humidity)
+    assert p.shape == t.shape == q.shape, 'pressure, temperature, specific_humidity must share a shape'
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    out, optr = _alloc((nlev, ncol), dt, dev, p)
+    L.check(lib.xp_dewpoint_from_specific_humidity(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)),
+                                                   C.byref(_view(q, nlev, ncol)), C.c_void_p(optr), _stream(dev)))
+    return out.reshape((nlev,) + hshape)
+
+
+def crossing_level(x, a, value):
+    """Smallest x over all intersections of the profile a(x) with the constant `value` (find_intersections
+    pf.py:992 + the min of pf.py:2153): freezing_level_height is crossing_level(height, temperature, 273.15)."""
+    (xh, ah), dt, dev = _common(x, a)
+    assert xh.shape == ah.shape
+    nlev, ncol, hshape = _vert_shape(xh)
+    lib = L.init(_device_of(xh))
+    out, optr = _alloc((ncol,), dt, dev, xh)
+    L.check(lib.xp_crossing_level(C.byref(_view(xh, nlev, ncol)), C.byref(_view(ah, nlev, ncol)), C.c_double(float(value)),
+                                  C.c_void_p(optr), _stream(dev)))
+    return out.reshape(hshape)
+
+
+def freezing_level_height(temperature, height):
+    """pf.py:2137."""
+    return crossing_level(height, temperature, 273.15)
+
+
+def wet_bulb_temperature_fast(temperature, dewpoint):
+    """pf.py:364: the "1/3 rule" estimate -- plain array arithmetic, no kernel of its own."""
+    return temperature - (1 / 3) * (temperature - dewpoint)
+
+
+def melting_level_height(pressure, temperature, dewpoint, height, fast=True, moist=None):
+    """pf.py:2160: freezing level of the wet-bulb temperature field; returns (height, wet bulb)."""
+    wb = wet_bulb_temperature_fast(temperature, dewpoint) if fast else \
+        wet_bulb_temperature(pressure, temperature, dewpoint, moist=moist)
+    return crossing_level(height, wb, 273.15), wb
+
+
+def isobar_temperature(pressure, temperature, isobar):
+    """pf.py:2193."""
+    return interp_level(pressure, temperature, isobar, log=True)
+
+
+def lapse_rate(pressure, temperature, height, from_pressure=700, to_pressure=500):
+    """pf.py:2102: (T_to - T_from) / (z_to - z_from) with z in km, all four by log-p interpolation."""
+    t0 = interp_level(pressure, temperature, from_pressure, log=True)
+    t1 = interp_level(pressure, temperature, to_pressure, log=True)
+    z0 = interp_level(pressure, height, from_pressure, log=True) / 1000
+    z1 = interp_level(pressure, height, to_pressure, log=True) / 1000
+    return (t1 - t0) / (z1 - z0)
+
+
+def deep_convective_index(pressure, temperature, dewpoint, lifted_index):
+    """pf.py:1830 (Kunz 2009): T850 + Td850 [deg C] - LI."""
+    t850 = interp_level(pressure, temperature, 850.0, log=True) - 273.15
+    td850 = interp_level(pressure, dewpoint, 850.0, log=True) - 273.15
+    return t850 + td850 - lifted_index
 
 
 def lifted_index(profile):

@@ -344,6 +344,81 @@ def lifted_index(profile, vert_dim=VERT, description=None, prefix=None):
     return Dataset({name: _horiz(_np(_api.lifted_index(prof)), dims, coords, attrs=attrs, name=name)})
 
 
+def wet_bulb_temperature_fast(temperature, dewpoint):
+    """pf.py:364: "1/3 rule" estimate (array arithmetic on the DataArrays, as in the reference)."""
+    wb = temperature - (1 / 3) * (temperature - dewpoint)
+    wb.name = 'wet_bulb_temperature'
+    wb.attrs['long_name'] = 'Wet bulb temperature'
+    wb.attrs['description'] = 'Estimated using 1/3 method.'
+    wb.attrs['units'] = 'K'
+    return wb
+
+
+def deep_convective_index(pressure, temperature, dewpoint, lifted_index, vert_dim=VERT, description=None, prefix=None):
+    """pf.py:1830 (Kunz 2009): T + Td at 850 hPa [deg C] minus the lifted index."""
+    p, dims, coords, _ = _split(pressure, vert_dim)
+    li = _split(lifted_index, vert_dim)[0]
+    dci = _np(_api.deep_convective_index(p, _split(temperature, vert_dim)[0], _split(dewpoint, vert_dim)[0], li))
+    attrs = {'long_name': 'Deep convective index', 'units': 'C'}
+    if description is not None:
+        attrs['description'] = description
+    name = 'dci' if prefix is None else prefix + '_dci'
+    return Dataset({name: _horiz(dci, dims, coords, attrs=attrs, name=name)})
+
+
+def lapse_rate(pressure, temperature, height, from_pressure=700, to_pressure=500, vert_dim=VERT):
+    """pf.py:2102: observed lapse rate between two pressure levels [K/km]."""
+    p, dims, coords, _ = _split(pressure, vert_dim)
+    out = _np(_api.lapse_rate(p, _split(temperature, vert_dim)[0], _split(height, vert_dim)[0],
+                              from_pressure=from_pressure, to_pressure=to_pressure))
+    return _horiz(out, dims, coords, attrs={'long_name': 'Lapse rate',
+                                            'description': f'{from_pressure}-{to_pressure} hPa lapse rate',
+                                            'units': 'K km$^{-1}$'})
+
+
+def freezing_level_height(temperature, height, vert_dim=VERT):
+    """pf.py:2137: height of the lowest 273.15 K crossing of the temperature profile."""
+    t, dims, coords, vc = _split(temperature, vert_dim)
+    _check_index(vc, 'Index increments must all be 1.')                                 # pf.py:1011
+    out = _np(_api.freezing_level_height(t, _split(height, vert_dim)[0]))
+    return _horiz(out, dims, coords, name='freezing_level',
+                  attrs={'long_name': 'Freezing-level height',
+                         'description': 'Height of zero degree dry-bulb temperature isotherm.', 'units': 'm'})
+
+
+def melting_level_height(pressure, temperature, dewpoint, height, fast=True, vert_dim=VERT):
+    """pf.py:2160: freezing level of the wet-bulb temperature; returns (melting level, wet bulb)."""
+    if fast:
+        wb = wet_bulb_temperature_fast(temperature=temperature, dewpoint=dewpoint)
+    else:
+        wb = wet_bulb_temperature(pressure=pressure, temperature=temperature, dewpoint=dewpoint, vert_dim=vert_dim)
+    mlh = freezing_level_height(temperature=wb, height=height, vert_dim=vert_dim)
+    mlh.attrs['long_name'] = 'Melting-level height'
+    mlh.attrs['description'] = 'Height of zero degree wet-bulb temperature isotherm.'
+    mlh.name = 'melting_level'
+    return mlh, wb
+
+
+def isobar_temperature(pressure, temperature, isobar, vert_dim=VERT):
+    """pf.py:2193."""
+    p, dims, coords, _ = _split(pressure, vert_dim)
+    out = _np(_api.isobar_temperature(p, _split(temperature, vert_dim)[0], isobar))
+    return _horiz(out, dims, coords, attrs={'description': f'Temperature at {isobar} hPa.',
+                                            'long_name': 'Isobar temperature', 'units': 'K'})
+
+
+def dewpoint_from_specific_humidity(pressure, temperature, specific_humidity, vert_dim=VERT):
+    """metpy.calc.dewpoint_from_specific_humidity (MetPy 1.4.1 chain) as the reference's harness and products call it
+    (parcel_test.py:262-266, pf.py:1889-1894), result in K."""
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    out = _np(_api.dewpoint_from_specific_humidity(p, _split(temperature, vert_dim)[0],
+                                                   _split(specific_humidity, vert_dim)[0]))
+    attrs = {'long_name': 'Dewpoint temperature', 'units': 'K'}
+    if vc is None:
+        return _horiz(out.reshape(p.shape), dims, coords, name='dewpoint', attrs=attrs)
+    return _vert(out, vert_dim, vc, dims, coords, name='dewpoint', attrs=attrs)
+
+
 # -- tables (pf.py:39-61) ------------------------------------------------------------------------------
 def load_moist_adiabat_lookups(**kwargs):
     """pf.py:39: make the reference-format lookup tables available to moist='table' calls."""
