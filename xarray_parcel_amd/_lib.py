@@ -74,23 +74,46 @@ class XParcelError(RuntimeError):
         self.code = code
 
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared']
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
+# translation units: the ABI + small kernels, and k_cape_cin once per (dtype, moist mode) -- see csrc/xp_cape_tu.hip
+UNITS = [('xparcel', 'xparcel.hip', [])] + [
+    (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}']) for t in ('double', 'float') for m in (0, 1, 2)]
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): the translation units in
+    parallel (hipcc -c), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [INCLUDE]
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    libdir = os.path.dirname(LIB_PATH)
+    objdir = os.path.join(libdir, 'obj%d' % os.getpid())
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    tmp = LIB_PATH + '.tmp%d' % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', tmp, os.path.join(SRC_DIR, 'xparcel.hip')]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB_PATH)           # atomic: a concurrent loader never sees a half-written library
+
+    def compile_unit(u):
+        name, src, defs = u
+        obj = os.path.join(objdir, name + '.o')
+        cmd = [hipcc] + HIPCC_FLAGS + defs + ['-c', os.path.join(SRC_DIR, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    try:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_unit, UNITS))
+        tmp = LIB_PATH + '.tmp%d' % os.getpid()
+        cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared', '-o', tmp] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB_PATH)       # atomic: a concurrent loader never sees a half-written library
+    finally:
+        import shutil
+        shutil.rmtree(objdir, ignore_errors=True)
     return LIB_PATH
 
 

@@ -1,0 +1,45 @@
+// One translation unit of libxparcel per (XP_TU_T, XP_TU_MODE): the k_cape_cin instantiations of that data type and
+// moist mode (4 parcel modes x profile on/off x dewpoint / specific-humidity input) and the launcher that picks one.
+// Compiled six times by the build (xarray_parcel_amd/_lib.py), e.g. -DXP_TU_T=double -DXP_TU_MODE=0.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "xp_kernels.hpp"
+
+#if !defined(XP_TU_T) || !defined(XP_TU_MODE)
+#error "compile with -DXP_TU_T=<float|double> -DXP_TU_MODE=<0|1|2>"
+#endif
+
+namespace xp {
+namespace {
+
+int cape_block() {             // XP_CAPE_BLOCK: workgroup size for experiments (64 / 128 / 256; default 256)
+    static int b = [] { const char *e = getenv("XP_CAPE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    return b;
+}
+
+template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool profile, hipStream_t s) {
+    const int b = cape_block();
+    dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
+    if (a.hum) {
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true>), gr, bl, 0, s, a);
+    } else {
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false>), gr, bl, 0, s, a);
+    }
+}
+
+}  // namespace
+
+template <> void launch_cape_mode<XP_TU_T, XP_TU_MODE>(const CapeArgs &a, int pm, bool profile, hipStream_t s) {
+    switch (pm) {
+        case PM_SURFACE: launch_t<XP_TU_T, PM_SURFACE, XP_TU_MODE>(a, profile, s); break;
+        case PM_MU: launch_t<XP_TU_T, PM_MU, XP_TU_MODE>(a, profile, s); break;
+        case PM_ML: launch_t<XP_TU_T, PM_ML, XP_TU_MODE>(a, profile, s); break;
+        default: launch_t<XP_TU_T, PM_EXPLICIT, XP_TU_MODE>(a, profile, s); break;
+    }
+}
+
+}  // namespace xp

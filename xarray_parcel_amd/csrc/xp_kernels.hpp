@@ -596,4 +596,8 @@ void k_crossing_level(View xv, View av, int64_t nlev, int64_t ncol, double value
     st(out, sizeof(T) == 8, c, best);
 }
 
+// host-side launcher of k_cape_cin<T, pm, profile, MODE, a.hum>, defined in xp_cape_tu.hip -- one translation unit per
+// (T, MODE), so that the 96 instantiations of the big kernel compile in parallel
+template <typename T, int MODE> void launch_cape_mode(const CapeArgs &a, int pm, bool profile, hipStream_t s);
+
 }  // namespace xp

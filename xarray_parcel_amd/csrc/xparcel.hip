@@ -193,30 +193,17 @@ int stage_scalars(Stager &st, xp_scalars_out *s, int64_t ncol, xp::ScalarsOut *o
     return rc;
 }
 
-int cape_block() {
-    static int b = [] { const char *e = getenv("XP_CAPE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
-    return b;
-}
-template <typename T, int PM, int MODE> void launch_cape_t(const xp::CapeArgs &a, bool profile, hipStream_t s) {
-    const int b = cape_block();
-    dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
-    if (a.hum) {
-        if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE, true>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE, true>), gr, bl, 0, s, a);
-    } else {
-        if (profile) hipLaunchKernelGGL((xp::k_cape_cin<T, PM, true, MODE, false>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((xp::k_cape_cin<T, PM, false, MODE, false>), gr, bl, 0, s, a);
-    }
-}
+// k_cape_cin's 96 instantiations are compiled in six translation units (xp_cape_tu.hip, one per dtype x moist mode) so
+// that the build parallelises; this file only dispatches to them.
 template <typename T, int PM> void launch_cape(const xp::CapeArgs &a, bool profile, hipStream_t s) {
     if (a.ncol == 0) return;
-    if (a.table_mode) launch_cape_t<T, PM, 1>(a, profile, s);
+    if (a.table_mode) xp::launch_cape_mode<T, 1>(a, PM, profile, s);
     else if (a.flags) {                                      // family mode: fast pass, then RK4 for the flagged columns
-        launch_cape_t<T, PM, 2>(a, profile, s);
+        xp::launch_cape_mode<T, 2>(a, PM, profile, s);
         xp::CapeArgs b = a;
         b.only_flagged = 1;
-        launch_cape_t<T, PM, 0>(b, profile, s);
-    } else launch_cape_t<T, PM, 0>(a, profile, s);
+        xp::launch_cape_mode<T, 0>(b, PM, profile, s);
+    } else xp::launch_cape_mode<T, 0>(a, PM, profile, s);
 }
 template <typename T> void launch_cape_pm(const xp::CapeArgs &a, int pm, bool profile, hipStream_t s) {
     switch (pm) {
