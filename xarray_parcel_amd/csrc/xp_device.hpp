@@ -500,30 +500,38 @@ struct Family {
 // NaN gaps -- sits behind one ballot-guarded branch.
 // Input contract used here (the reference's, README.md:9 / pf.py:2319-2320): pressure decreases with the node
 // index, so "the lowest pressure where both temperatures exist" (pf.py:1143-1147) is the LAST such node.
+// Values that are written a few times per column (at the LCL node, at sign changes) and read once (in finish) live in
+// LDS, one slot per thread, instead of occupying VGPRs through the level loop: field f of thread t at slot[f * 256 + t].
+constexpr int SLOT_STRIDE = 256, SLOT_FIELDS = 10;
+enum { SL_CAPE_LCL = 0, SL_CIN_LCL, SL_CAPE_LFC, SL_CIN_LFC, SL_CAPE_EL, SL_LFC_T, SL_EL_T, SL_LCL_T, SL_LFC_IDX, SL_EL_IDX };
+
 struct Scan {
     // configuration
     double p_lcl, x_lcl;   // LCL pressure and its logarithm (the X of the LCL node)
     bool pos_neg;
+    double *slot;          // this thread's LDS slots (SLOT_FIELDS doubles, stride SLOT_STRIDE)
     // previous node
     double Xp, yp, parp;
     int j;                 // nodes seen so far
     bool use_all;          // env[0] != par[0] (pf.py:1117-1120)
-    // prefix sums and snapshots
-    double cape, cin, cape_lcl, cin_lcl, cape_lfc, cin_lfc, cape_el;
+    // prefix sums (their snapshots at the LCL node / LFC / EL are in the slots)
+    double cape, cin;
     // crossings, kept as ln p: pressures decrease along the scan, so "bottom LFC" / "top EL" order the same in ln p,
     // and the two exponentials a column actually needs are taken once, in finish()
-    double lfc_x, lfc_t, el_x, el_t;
-    int lfc_idx, el_idx;
+    double lfc_x, el_x;
     bool any_inc, pos_parcel, env_any;
-    double top_par, top_env, min_p;
+    bool top_le, any_valid;  // at the last node where p, parcel, environment all exist: parcel <= environment; there is one
+    double min_p;
 
-    XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_) {
-        p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_;
+    XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_, double *slot_) {
+        p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_; slot = slot_;
         Xp = yp = parp = qnan(); j = 0; use_all = true;
-        cape = cin = cape_lcl = cin_lcl = cape_lfc = cin_lfc = cape_el = 0.0;
-        lfc_x = lfc_t = el_x = el_t = qnan(); lfc_idx = el_idx = -1;
-        any_inc = pos_parcel = env_any = false;
-        top_par = top_env = min_p = qnan();
+        cape = cin = 0.0;
+        for (int f = 0; f < SLOT_FIELDS; ++f)
+            slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T) ? qnan() : (f == SL_LFC_IDX || f == SL_EL_IDX) ? -1.0 : 0.0;
+        lfc_x = el_x = qnan();
+        any_inc = pos_parcel = env_any = top_le = any_valid = false;
+        min_p = qnan();
     }
     XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
         if (pos_neg) { cape += fmax(a, 0.0); cin += fmin(a, 0.0); }      // maxNum/minNum drop a NaN operand
@@ -578,11 +586,13 @@ struct Scan {
             if (y > 0.0 && in_sel) {                                        // increasing crossing
                 any_inc = true;
                 if (above && !(xs <= lfc_x)) {                              // bottom LFC above the LCL (pf.py:1127-1132)
-                    lfc_x = xs; lfc_t = ys; lfc_idx = i; cape_lfc = cape; cin_lfc = cin;
+                    lfc_x = xs; slot[SL_LFC_IDX * SLOT_STRIDE] = (double)i;
+                    slot[SL_LFC_T * SLOT_STRIDE] = ys; slot[SL_CAPE_LFC * SLOT_STRIDE] = cape; slot[SL_CIN_LFC * SLOT_STRIDE] = cin;
                 }
             }
             if (y < 0.0 && i >= 1 && !(xs >= el_x)) {                       // top EL (pf.py:1136-1138)
-                el_x = xs; el_t = ys; el_idx = i; cape_el = cape;
+                el_x = xs; slot[SL_EL_IDX * SLOT_STRIDE] = (double)i;
+                slot[SL_EL_T * SLOT_STRIDE] = ys; slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
             }
         }
         add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
@@ -597,30 +607,35 @@ struct Scan {
         pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);
-        bool valid = pv && !isnan_(par) && !isnan_(env);
+        bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
         min_p = pv ? P : min_p;
-        top_par = valid ? par : top_par;
-        top_env = valid ? env : top_env;
-        if (is_lcl) { cape_lcl = cape; cin_lcl = cin; }
+        top_le = valid ? (par <= env) : top_le;
+        any_valid = any_valid || valid;
+        if (is_lcl) { slot[SL_CAPE_LCL * SLOT_STRIDE] = cape; slot[SL_CIN_LCL * SLOT_STRIDE] = cin; }
         Xp = X; yp = y; parp = par; ++j;
     }
     struct Result { double cape, cin, lfc_p, lfc_t, el_p, el_t; int lfc_idx, el_idx, status; };
-    XP_DEV Result finish(double lcl_t, bool post_zero) {
+    XP_DEV Result finish(bool post_zero) {      // slot[SL_LCL_T]: the LCL (virtual) temperature, set by the caller
         Result r;
         r.status = 0;
+        const double lcl_t = slot[SL_LCL_T * SLOT_STRIDE];
+        int lfc_idx = (int)slot[SL_LFC_IDX * SLOT_STRIDE], el_idx = (int)slot[SL_EL_IDX * SLOT_STRIDE];
         double lfc_p = crossing_pressure(lfc_x), el_p = crossing_pressure(el_x);
+        double lfc_t = slot[SL_LFC_T * SLOT_STRIDE], el_t = slot[SL_EL_T * SLOT_STRIDE];
         // EL exists only if the parcel ends colder than the environment and the EL is above the LCL
-        bool el_ok = (top_par <= top_env) && (el_p < p_lcl);                    // pf.py:1151-1155
+        bool el_ok = top_le && (el_p < p_lcl);                                  // pf.py:1151-1155
         if (!el_ok) { el_p = qnan(); el_t = qnan(); el_idx = -1; }
-        if (isnan_(top_env) && env_any) r.status |= 1;                          // assert of pf.py:1149
+        if (!any_valid && env_any) r.status |= 1;                               // assert of pf.py:1149
         bool lfc_missing = !any_inc;
         bool replace = (pos_parcel && lfc_missing) ||
                        (!lfc_missing && isnan_(lfc_p) && (el_p < p_lcl));       // pf.py:1161-1180
         double L, cL, nL;
-        if (replace) { L = p_lcl; cL = cape_lcl; nL = cin_lcl; lfc_p = p_lcl; lfc_t = lcl_t; lfc_idx = -2; }
-        else { L = lfc_p; cL = cape_lfc; nL = cin_lfc; }
+        if (replace) {
+            L = p_lcl; cL = slot[SL_CAPE_LCL * SLOT_STRIDE]; nL = slot[SL_CIN_LCL * SLOT_STRIDE];
+            lfc_p = p_lcl; lfc_t = lcl_t; lfc_idx = -2;
+        } else { L = lfc_p; cL = slot[SL_CAPE_LFC * SLOT_STRIDE]; nL = slot[SL_CIN_LFC * SLOT_STRIDE]; }
         double E = el_ok ? el_p : min_p;                                        // pf.py:1329
-        double cE = el_ok ? cape_el : cape;
+        double cE = el_ok ? slot[SL_CAPE_EL * SLOT_STRIDE] : cape;
         r.cape = (E < L) ? RD * (cE - cL) : 0.0;                                // NaN LFC -> comparisons false -> 0.0
         r.cin = isnan_(L) ? 0.0 : RD * nL;
         if (post_zero && !(r.cin <= 0.0)) r.cin = 0.0;                          // pf.py:1387-1388

@@ -147,7 +147,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
-__global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE || HUM) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
     // 3 waves/SIMD = 168 VGPRs: SB gets there unforced (164); the MU / ML / explicit variants sit at 170-180 and are held to it
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE 
     st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
     sti(s.parcel_idx, c, pc.idx);
     st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
-    const double lcl_t_arg = a.vtc ? l.tv : l.t;                           // pf.py:1442 / 1461
     const double w_parcel = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0; // pf.py:748
     // ln p bookkeeping.  Levels use the table logarithm; the LCL node uses the library log (its crossing tests
     // "p* < p_lcl" then break ties as on the CPU); a level that sits exactly on the LCL pressure takes the LCL's
@@ -210,7 +209,9 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE 
     const double x_lcl = log(l.p);
     const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
 
-    Scan sc; sc.init(l.p, x_lcl, a.pos_neg != 0);
+    __shared__ double s_slot[SLOT_FIELDS * SLOT_STRIDE];
+    Scan sc; sc.init(l.p, x_lcl, a.pos_neg != 0, s_slot + threadIdx.x);
+    sc.slot[SL_LCL_T * SLOT_STRIDE] = a.vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
     Moist m;
     Family fam;
     if (FAMILY) fam.start(a.fam_tab, x_lcl, l.t, dt_dlnp_e(l.p, l.t, es_tab(es, l.t)));
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PMODE != PM_SURFACE || PROFILE 
         }
     }
 
-    Scan::Result r = sc.finish(lcl_t_arg, a.post_zero != 0);
+    Scan::Result r = sc.finish(a.post_zero != 0);
     status |= r.status;
     if (FAMILY) a.flags[c] = fam.bad ? 1 : 0;
     st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
@@ -457,12 +458,14 @@ void k_lfc_el(View pv, View parv, View envv, int64_t nlev, int64_t ncol, const v
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     double lp = ld1<T>(lcl_p, c), lt = ld1<T>(lcl_t, c);
-    Scan sc; sc.init(lp, log(lp), true);
+    __shared__ double s_slot[SLOT_FIELDS * SLOT_STRIDE];
+    Scan sc; sc.init(lp, log(lp), true, s_slot + threadIdx.x);
+    sc.slot[SL_LCL_T * SLOT_STRIDE] = lt;
     for (int64_t k = 0; k < nlev; ++k) {
         double P = ld<T>(pv, k, c);
         sc.node(P, flog(P), ld<T>(parv, k, c), ld<T>(envv, k, c), false);
     }
-    Scan::Result r = sc.finish(lt, false);
+    Scan::Result r = sc.finish(false);
     st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t); st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
     sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, r.status);
 }
