@@ -110,19 +110,21 @@ __device__ __attribute__((noinline)) double log_slow(double x) { return log(x); 
 
 // ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
 // The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
-// exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a 10 KB table into LDS:
-// 160 one-kelvin intervals over 170..330 K, a degree-7 polynomial in r = T - centre each (Chebyshev
+// exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a table into LDS:
+// 193 one-kelvin intervals over 137..330 K, a degree-7 polynomial in r = T - centre each (Chebyshev
 // interpolant of Bolton's formula built in long double by xp_init; relative error < 3e-15), stored
 // coefficient-major so that the lanes of a wavefront -- whose temperatures fall in different intervals --
 // hit different LDS banks.  Out-of-range or NaN temperatures take the formula.
-constexpr double ES_T_LO = 120.0;
+constexpr double ES_T_LO = 137.0;
 // Row stride 257 doubles: (a) more than the 255 x 8 B reach of ds_read2_b64 and not a multiple of 64, so every
 // coefficient is its own ds_read_b64 (2 LDS cycles, banks (a/4) mod 64) instead of half a ds_read2_b64 (8 cycles per
 // pair, banks mod 32: measured 48 % of all LDS cycles were bank conflicts with the merged reads); (b) odd, so that
-// row c is rotated by c banks against row 0.
-constexpr int ES_N = 210, ES_DEG = 7, ES_STRIDE = 257, ES_TAB = (ES_DEG + 1) * ES_STRIDE;
-constexpr int LOG_N = 64, LOG_TAB = 2 * ES_STRIDE;  // ln table: 1/c_i and ln c_i for 64 mantissa intervals, same row stride
-constexpr int LDS_TAB = ES_TAB + LOG_TAB;
+// row c is rotated by c banks against row 0.  193 intervals (137 ... 330 K) leave 64 spare columns per row: rows 0 and 1
+// carry the ln table there (1/c_i and ln c_i for 64 mantissa intervals), and the last row ends after its 193 entries
+// -- 15.9 KB in all, which together with the scan's LDS slots lets four workgroups share a CU.
+constexpr int ES_N = 193, ES_DEG = 7, ES_STRIDE = 257, ES_TAB = ES_DEG * ES_STRIDE + ES_N;
+constexpr int LOG_N = 64, LOG_OFF = ES_N;           // ln table: tb[LOG_OFF + i] = 1/c_i, tb[ES_STRIDE + LOG_OFF + i] = ln c_i
+constexpr int LDS_TAB = ES_TAB;
 // `all_in_range` is a wave-uniform promise by the caller that every lane's t lies inside the table (the per-level
 // code tests T, Td and the parcel temperature once per level with margins, see in_table()); without it the
 // range test is made here and out-of-table / NaN lanes take the formula.
@@ -161,7 +163,7 @@ XP_DEV bool in_table(double t, double margin) { return (t >= ES_T_LO + margin) &
 // ln(x) from the LDS table that follows the e_s table: x = 2^e m, m in [0.5,1) = c_i (1 + r), |r| < 2^-7;
 // ln x = e ln2 + ln c_i + log1p(r), log1p by its series to r^7 (< 2e-18).  Positive finite x (NaN -> NaN).
 XP_DEV double log_tab(const double *tb, double x) {
-    const double *lt = tb + ES_TAB;
+    const double *lt = tb + LOG_OFF;
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);
     int i = (int)(m * 128.0) - 64;
@@ -502,8 +504,14 @@ struct Family {
 // index, so "the lowest pressure where both temperatures exist" (pf.py:1143-1147) is the LAST such node.
 // Values that are written a few times per column (at the LCL node, at sign changes) and read once (in finish) live in
 // LDS, one slot per thread, instead of occupying VGPRs through the level loop: field f of thread t at slot[f * 256 + t].
-constexpr int SLOT_STRIDE = 256, SLOT_FIELDS = 10;
-enum { SL_CAPE_LCL = 0, SL_CIN_LCL, SL_CAPE_LFC, SL_CIN_LFC, SL_CAPE_EL, SL_LFC_T, SL_EL_T, SL_LCL_T, SL_LFC_IDX, SL_EL_IDX };
+constexpr int SLOT_STRIDE = 256, SLOT_FIELDS = 12;
+// SL_A0..A3 are used twice: below the LCL they hold the lower bracket of the LCL interpolation (kernel side:
+// pressure, ln p, T, Td of the last valid level), from the LCL node on the bottom-LFC record -- an LFC has to lie
+// above the LCL (pf.py:1127-1132), so the two never coexist; the LCL node re-initialises them.
+enum { SL_CAPE_LCL = 0, SL_CIN_LCL, SL_MIN_P, SL_IDX /* two int32: lfc index, el index */, SL_LCL_T,
+       SL_A0, SL_A1, SL_A2, SL_A3, SL_EL_X, SL_EL_T, SL_CAPE_EL,
+       SL_BR_P = SL_A0, SL_BR_X = SL_A1, SL_BR_T = SL_A2, SL_BR_TD = SL_A3,
+       SL_LFC_X = SL_A0, SL_LFC_T = SL_A1, SL_CAPE_LFC = SL_A2, SL_CIN_LFC = SL_A3 };
 
 struct Scan {
     // configuration
@@ -518,21 +526,19 @@ struct Scan {
     double cape, cin;
     // crossings, kept as ln p: pressures decrease along the scan, so "bottom LFC" / "top EL" order the same in ln p,
     // and the two exponentials a column actually needs are taken once, in finish()
-    double lfc_x, el_x;
     bool any_inc, pos_parcel, env_any;
     bool top_le, any_valid;  // at the last node where p, parcel, environment all exist: parcel <= environment; there is one
-    double min_p;
 
     XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_, double *slot_) {
         p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_; slot = slot_;
         Xp = yp = parp = qnan(); j = 0; use_all = true;
         cape = cin = 0.0;
         for (int f = 0; f < SLOT_FIELDS; ++f)
-            slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T) ? qnan() : (f == SL_LFC_IDX || f == SL_EL_IDX) ? -1.0 : 0.0;
-        lfc_x = el_x = qnan();
+            slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T || f == SL_LFC_X || f == SL_EL_X || f == SL_MIN_P) ? qnan() : 0.0;
+        idx()[0] = -1; idx()[1] = -1;
         any_inc = pos_parcel = env_any = top_le = any_valid = false;
-        min_p = qnan();
     }
+    XP_DEV int *idx() const { return (int *)(slot + SL_IDX * SLOT_STRIDE); }     // [0] lfc index, [1] el index
     XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
         if (pos_neg) { cape += fmax(a, 0.0); cin += fmin(a, 0.0); }      // maxNum/minNum drop a NaN operand
         else { double b = isnan_(a) ? 0.0 : a; cape += b; cin += b; }
@@ -585,19 +591,24 @@ struct Scan {
             bool in_sel = use_all || i >= 1;
             if (y > 0.0 && in_sel) {                                        // increasing crossing
                 any_inc = true;
-                if (above && !(xs <= lfc_x)) {                              // bottom LFC above the LCL (pf.py:1127-1132)
-                    lfc_x = xs; slot[SL_LFC_IDX * SLOT_STRIDE] = (double)i;
+                if (above && !(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {        // bottom LFC above the LCL (pf.py:1127-1132)
+                    slot[SL_LFC_X * SLOT_STRIDE] = xs; idx()[0] = i;
                     slot[SL_LFC_T * SLOT_STRIDE] = ys; slot[SL_CAPE_LFC * SLOT_STRIDE] = cape; slot[SL_CIN_LFC * SLOT_STRIDE] = cin;
                 }
             }
-            if (y < 0.0 && i >= 1 && !(xs >= el_x)) {                       // top EL (pf.py:1136-1138)
-                el_x = xs; slot[SL_EL_IDX * SLOT_STRIDE] = (double)i;
+            // top EL (pf.py:1136-1138); one at or below the LCL would be discarded by finish() anyway (pf.py:1151-1155)
+            if (y < 0.0 && i >= 1 && above && !(xs >= slot[SL_EL_X * SLOT_STRIDE])) {
+                slot[SL_EL_X * SLOT_STRIDE] = xs; idx()[1] = i;
                 slot[SL_EL_T * SLOT_STRIDE] = ys; slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
             }
         }
         add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
     }
     XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
+        if (is_lcl) {                                                       // the bracket is spent: SL_A* become the LFC record
+            slot[SL_LFC_X * SLOT_STRIDE] = qnan(); slot[SL_LFC_T * SLOT_STRIDE] = qnan();
+            slot[SL_CAPE_LFC * SLOT_STRIDE] = 0.0; slot[SL_CIN_LFC * SLOT_STRIDE] = 0.0;
+        }
         double y = par - env;
         // same sign <=> y*yp > 0 or both zero; NaN (and the first node, yp = NaN) is "not same"
         bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
@@ -608,7 +619,7 @@ struct Scan {
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
-        min_p = pv ? P : min_p;
+        if (pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                           // lowest valid pressure so far = the last one
         top_le = valid ? (par <= env) : top_le;
         any_valid = any_valid || valid;
         if (is_lcl) { slot[SL_CAPE_LCL * SLOT_STRIDE] = cape; slot[SL_CIN_LCL * SLOT_STRIDE] = cin; }
@@ -619,8 +630,9 @@ struct Scan {
         Result r;
         r.status = 0;
         const double lcl_t = slot[SL_LCL_T * SLOT_STRIDE];
-        int lfc_idx = (int)slot[SL_LFC_IDX * SLOT_STRIDE], el_idx = (int)slot[SL_EL_IDX * SLOT_STRIDE];
-        double lfc_p = crossing_pressure(lfc_x), el_p = crossing_pressure(el_x);
+        int lfc_idx = idx()[0], el_idx = idx()[1];
+        double lfc_p = crossing_pressure(slot[SL_LFC_X * SLOT_STRIDE]), el_p = crossing_pressure(slot[SL_EL_X * SLOT_STRIDE]);
+        const double min_p = slot[SL_MIN_P * SLOT_STRIDE];
         double lfc_t = slot[SL_LFC_T * SLOT_STRIDE], el_t = slot[SL_EL_T * SLOT_STRIDE];
         // EL exists only if the parcel ends colder than the environment and the EL is above the LCL
         bool el_ok = top_le && (el_p < p_lcl);                                  // pf.py:1151-1155

@@ -236,11 +236,15 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void 
     };
 
     bool lcl_done = false;
-    double pb = qnan(), xb = qnan(), tb_ = qnan(), tdb = qnan();          // last valid-pressure node at or below the LCL
+    // last valid-pressure node at or below the LCL (the lower bracket of the LCL interpolation): LDS slots, written in
+    // phase A only
+    double *const br = sc.slot;
+    br[SL_BR_P * SLOT_STRIDE] = qnan(); br[SL_BR_X * SLOT_STRIDE] = qnan(); br[SL_BR_T * SLOT_STRIDE] = qnan(); br[SL_BR_TD * SLOT_STRIDE] = qnan();
     auto emit_lcl = [&](double pa, double xa, double ta, double tda) __attribute__((always_inline)) {
         // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811),
         // then virtual temperature recomputed from the interpolated T, Td (pf.py:911-920)
         double at = a.log_interp ? x_lcl : l.p;
+        const double pb = br[SL_BR_P * SLOT_STRIDE], xb = br[SL_BR_X * SLOT_STRIDE], tb_ = br[SL_BR_T * SLOT_STRIDE], tdb = br[SL_BR_TD * SLOT_STRIDE];
         double cb = a.log_interp ? xb : pb, ca = a.log_interp ? xa : pa;
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
@@ -253,7 +257,10 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void 
             tve = virt(te, mixing_ratio_tab(es, te, tde, l.p));
             if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = te; asm volatile("" : "+v"(q)); tve = virt_ref(q, tde, l.p); }
         }
-        emit(l.p, x_lcl, l.t, l.tv, te, tve, tde, true);
+        // without profile output the scan only sees the temperature picked by the correction switch, which sits in
+        // the SL_LCL_T slot: neither LCL temperature has to stay in registers through the loop
+        const double lsel = br[SL_LCL_T * SLOT_STRIDE];
+        emit(l.p, x_lcl, PROFILE ? l.t : lsel, PROFILE ? l.tv : lsel, te, tve, tde, true);
         lcl_done = true;
     };
     // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void 
             tve = virt_ref(T_, Td_, P);
         }
         emit(P, X, tp, tvp, T_, tve, Td_, false);
-        if (!isnan_(P) && !lcl_done) { pb = P; xb = X; tb_ = T_; tdb = Td_; }
+        if (!isnan_(P) && !lcl_done) { br[SL_BR_P * SLOT_STRIDE] = P; br[SL_BR_X * SLOT_STRIDE] = X; br[SL_BR_T * SLOT_STRIDE] = T_; br[SL_BR_TD * SLOT_STRIDE] = Td_; }
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)

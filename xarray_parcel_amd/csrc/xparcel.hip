@@ -71,7 +71,7 @@ void build_es_table(double *out) {
         for (int j = 0; j < n; ++j) out[j * xp::ES_STRIDE + i] = (double)(A[j][n] / A[j][j]);
     }
     // ln table for xp::log_tab: mantissa interval i of [0.5, 1) has centre c_i = (i + 64.5) / 128
-    double *lt = out + xp::ES_TAB;
+    double *lt = out + xp::LOG_OFF;                    // spare columns of rows 0 (1/c_i) and 1 (ln c_i)
     for (int i = 0; i < xp::LOG_N; ++i) {
         LD c = ((LD)i + 64.5L) / 128.0L;
         lt[i] = (double)(1.0L / c);
