@@ -147,8 +147,10 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
-__global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void k_cape_cin(CapeArgs a) {
-    // 3 waves/SIMD = 168 VGPRs: SB gets there unforced (164); the MU / ML / explicit variants sit at 170-180 and are held to it
+__global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE == PM_SURFACE ? 1 : 4))) void k_cape_cin(CapeArgs a) {
+    // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
+    // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
+    // with 32-48 B of scratch, still a net gain); profile output, q input and the family mode stay at 3 waves (168).
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void 
     if (FAMILY) fam.start(a.fam_tab, x_lcl, l.t, dt_dlnp_e(l.p, l.t, es_tab(es, l.t)));
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
-    int64_t jout = 0;                                                      // profile row
+    int jout = 0;                                                           // profile row
     auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
             if (jout < a.prof.nlev_out) {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : 1)) void 
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
-    int64_t k = pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
+    int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
     // software-prefetched level loop
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
