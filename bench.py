@@ -191,7 +191,9 @@ def main():
                        'multi_gpu': 'y-slab per rank + one RCCL gather of (cape, cin) per step' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a.nlev, a.ny, a.nx, a.dtype),
-                         'kernel': 'xp::k_cape_cin<double, 0, false, 0, false>' if a.dtype == 'f64' else 'xp::k_cape_cin<float, 0, false, false>',
+                         'kernel': 'xp::k_cape_cin<%s, 0, false, %d, %s>' % ('double' if a.dtype == 'f64' else 'float',
+                                                                            {'exact': 0, 'family': 2}[a.moist],
+                                                                            'true' if a.humidity == 'specific' else 'false'),
                          'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch},
             'check': {'max_cape': float(last['cape'].max()), 'min_cin': float(last['cin'].min())},
         }
