@@ -73,8 +73,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=0, help='columns for the CPU baseline (0 = auto)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
-    ap.add_argument('--moist', default='exact', choices=['exact', 'family'],
-                    help='exact = RK4 stepper; family = same ODE from the adiabat-family table (xparcel.h)')
+    ap.add_argument('--moist', default='exact', choices=['exact', 'family', 'table'],
+                    help='exact = RK4 stepper (headline); family = same ODE from the adiabat-family table (xparcel.h); '
+                         'table = the reference\'s lookup tables (pf.py:525-607), generated on the GPU before the timed region')
     ap.add_argument('--humidity', default='dewpoint', choices=['dewpoint', 'specific'],
                     help="'specific': feed specific humidity and convert on load (XP_HUM_SPECIFIC); not the headline")
     ap.add_argument('--nlev', type=int, default=NLEV)
@@ -124,6 +125,9 @@ def main():
         w = 0.6219569100577033 * e / (p - e)
         td = (w / (1.0 + w)).to(tdt)
         del e, w
+    if a.moist == 'table':
+        from xarray_parcel_amd import adiabat_tables
+        adiabat_tables.load_moist_adiabat_lookups(cache=False)
     want = ('cape', 'cin')
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered = [torch.empty((world, 2, ncol), dtype=tdt, device=cdev) for _ in range(2)] if (world > 1 and rank == 0) else None
@@ -192,7 +196,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a.nlev, a.ny, a.nx, a.dtype),
                          'kernel': 'xp::k_cape_cin<%s, 0, false, %d, %s>' % ('double' if a.dtype == 'f64' else 'float',
-                                                                            {'exact': 0, 'family': 2}[a.moist],
+                                                                            {'exact': 0, 'table': 1, 'family': 2}[a.moist],
                                                                             'true' if a.humidity == 'specific' else 'false'),
                          'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch},
             'check': {'max_cape': float(last['cape'].max()), 'min_cin': float(last['cin'].min())},
