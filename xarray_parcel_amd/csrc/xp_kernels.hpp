@@ -266,14 +266,18 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE ==
         lcl_done = true;
     };
     // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
-    auto moist_node = [&](double P, double X, double T_, double Td_) __attribute__((always_inline)) {
+    // `Q`: with specific-humidity input and no profile output the environment's mixing ratio is q / (1 - q) itself --
+    // the reference's w = RH * w_s(p, T) with RH = e_s(Td) / e_s(T) (pf.py:698-704) undoes exactly the q -> Td chain --
+    // so above the LCL neither the dewpoint nor the two e_s evaluations are needed (m_ then holds q, not Td)
+    auto moist_node = [&](double P, double X, double T_, double m_, bool Q) __attribute__((always_inline)) {
         // one wave-uniform range test per level instead of one per e_s evaluation
-        bool fast = __builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull;
+        bool fast = __builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && (Q || in_table(m_, 0.0)))) == 0ull;
         double tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);           // NaN pressure -> NaN
         double w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;      // pf.py:760
         double tvp = need_w ? virt(tp, w) : tp;
-        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P, fast)) : T_;   // pf.py:839-843
-        emit(P, X, tp, tvp, T_, tve, Td_, false);
+        double we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, fast);
+        double tve = need_w ? virt(T_, we) : T_;                                         // pf.py:839-843
+        emit(P, X, tp, tvp, T_, tve, m_, false);
     };
     auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
         if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
@@ -321,9 +325,10 @@ __global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE ==
         source(P, T_, Td_);
     }
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
-        double P = np_, T_ = nt_, Td_ = as_dewpoint<HUM>(es, np_, nt_, ntd_);
+        constexpr bool Q = HUM && !PROFILE;
+        double P = np_, T_ = nt_, m_ = Q ? ntd_ : as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
-        moist_node(P, log_tab(es, P), T_, Td_);
+        moist_node(P, log_tab(es, P), T_, m_, Q);
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (PROFILE) {
