@@ -15,7 +15,7 @@ namespace xp {
 namespace {
 
 int cape_block() {             // XP_CAPE_BLOCK: workgroup size for experiments (64 / 128 / 256; default 256)
-    static int b = [] { const char *e = getenv("XP_CAPE_BLOCK"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();
+    static int b = [] { const char *e = getenv("XP_CAPE_BLOCK"); int v = e ? atoi(e) : XP_CAPE_THREADS; return (v == 64 || v == 128 || v == 256 || v == XP_CAPE_THREADS) ? v : XP_CAPE_THREADS; }();
     return b;
 }
 

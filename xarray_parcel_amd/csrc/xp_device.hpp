@@ -504,7 +504,10 @@ struct Family {
 // index, so "the lowest pressure where both temperatures exist" (pf.py:1143-1147) is the LAST such node.
 // Values that are written a few times per column (at the LCL node, at sign changes) and read once (in finish) live in
 // LDS, one slot per thread, instead of occupying VGPRs through the level loop: field f of thread t at slot[f * 256 + t].
-constexpr int SLOT_STRIDE = 256, SLOT_FIELDS = 12;
+#ifndef XP_CAPE_THREADS
+#define XP_CAPE_THREADS 256
+#endif
+constexpr int SLOT_STRIDE = XP_CAPE_THREADS, SLOT_FIELDS = 12;
 // SL_A0..A3 are used twice: below the LCL they hold the lower bracket of the LCL interpolation (kernel side:
 // pressure, ln p, T, Td of the last valid level), from the LCL node on the bottom-LFC record -- an LFC has to lie
 // above the LCL (pf.py:1127-1132), so the two never coexist; the LCL node re-initialises them.

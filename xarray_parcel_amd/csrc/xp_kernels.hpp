@@ -147,7 +147,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
-__global__ __launch_bounds__(256, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE == PM_SURFACE ? 1 : 4))) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE == PM_SURFACE ? 1 : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
     // with 32-48 B of scratch, still a net gain); profile output, q input and the family mode stay at 3 waves (168).
@@ -466,7 +466,7 @@ void k_parcel_profile(View pv, int64_t nlev, int64_t ncol, const void *pp, const
 }
 
 // lfc_el (pf.py:1066-1198) on caller-supplied profiles: the same state machine, fed directly
-template <typename T> __global__ __launch_bounds__(256)
+template <typename T> __global__ __launch_bounds__(XP_CAPE_THREADS)
 void k_lfc_el(View pv, View parv, View envv, int64_t nlev, int64_t ncol, const void *lcl_p, const void *lcl_t,
               ScalarsOut s) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
