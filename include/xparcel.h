@@ -84,7 +84,8 @@ typedef struct {
     int32_t dtype;      /* XP_F32 | XP_F64 */
     int32_t mem;        /* XP_MEM_HOST | XP_MEM_DEVICE */
     int64_t nlev, ncol;
-    int64_t lev_stride, col_stride; /* in elements */
+    int64_t lev_stride, col_stride; /* in elements.  xp_cape_cin is fastest when its three views share their strides
+                                       (non-negative, < 4 GiB per level row): anything else is copied to dense scratch first */
 } xp_view;
 
 typedef struct {

@@ -278,6 +278,16 @@ def test_strided_device_views_through_the_raw_abi():
     torch.cuda.synchronize()
     assert np.array_equal(cape.cpu().numpy(), dense['cape']) and np.array_equal(cin.cpu().numpy(), dense['cin'])
     assert np.array_equal(idx.cpu().numpy(), dense['lfc_index'])
+    # views that do NOT share their strides (temperature level-major, the other two column-major): densified on the
+    # device inside the call, same answer; most-unstable parcel so that the pre-scan reads them too
+    dense_mu = xa.cape_cin_columns(p, t, td, parcel='most_unstable', want=('cape', 'cin', 'lfc_index'))
+    t_lm = torch.from_numpy(t).cuda()
+    mixed = [views[0], L.View(t_lm.data_ptr(), L.XP_F64, L.XP_MEM_DEVICE, nlev, ncol, ncol, 1), views[2]]
+    pc_mu = L.Parcel(L.PARCEL['most_unstable'], 0, 300.0, None, None, None)
+    L.check(lib.xp_cape_cin(C.byref(mixed[0]), C.byref(mixed[1]), C.byref(mixed[2]), C.byref(pc_mu), C.byref(o),
+                            C.byref(so), None, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(cape.cpu().numpy(), dense_mu['cape']) and np.array_equal(idx.cpu().numpy(), dense_mu['lfc_index'])
     o32 = L.Opts(1, 1, 1, 0, 0, L.XP_F32, 0, 0)
     assert lib.xp_cape_cin(C.byref(views[0]), C.byref(views[1]), C.byref(views[2]), C.byref(pc), C.byref(o32),
                            C.byref(so), None, None) == -1                 # XP_E_ARG: fp32 arithmetic not implemented

@@ -122,7 +122,10 @@ constexpr double ES_T_LO = 137.0;
 // row c is rotated by c banks against row 0.  193 intervals (137 ... 330 K) leave 64 spare columns per row: rows 0 and 1
 // carry the ln table there (1/c_i and ln c_i for 64 mantissa intervals), and the last row ends after its 193 entries
 // -- 15.9 KB in all, which together with the scan's LDS slots lets four workgroups share a CU.
-constexpr int ES_N = 193, ES_DEG = 7, ES_STRIDE = 257, ES_TAB = ES_DEG * ES_STRIDE + ES_N;
+#ifndef XP_ES_DEG
+#define XP_ES_DEG 7
+#endif
+constexpr int ES_N = 193, ES_DEG = XP_ES_DEG, ES_STRIDE = 257, ES_TAB = ES_DEG * ES_STRIDE + ES_N;
 constexpr int LOG_N = 64, LOG_OFF = ES_N;           // ln table: tb[LOG_OFF + i] = 1/c_i, tb[ES_STRIDE + LOG_OFF + i] = ln c_i
 constexpr int LDS_TAB = ES_TAB;
 // `all_in_range` is a wave-uniform promise by the caller that every lane's t lies inside the table (the per-level
@@ -138,8 +141,8 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     }
     double r = u - ((double)i + 0.5);
     const double *c = tb + i;
-    double p = c[7 * ES_STRIDE];
-    p = __builtin_fma(p, r, c[6 * ES_STRIDE]);
+    double p = c[ES_DEG * ES_STRIDE];
+    if (ES_DEG >= 7) p = __builtin_fma(p, r, c[6 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[5 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[4 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[3 * ES_STRIDE]);

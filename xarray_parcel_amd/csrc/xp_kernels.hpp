@@ -38,6 +38,7 @@ struct CapeArgs {
     double depth;
     int vtc, log_interp, pos_neg, post_zero, table_mode;
     int hum;                              // 1: the td view holds specific humidity (host side: picks the HUM instantiation)
+    int off32;                            // 1: the three views share strides and a column's byte offset within a level fits 32 bits
     Tables tb;
     const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
     const double *fam_tab;                // adiabat-family table [FAM_NX][FAM_NS] (family mode)
@@ -317,17 +318,27 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE || HUM) ? 3
     int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
     // software-prefetched level loop
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
-    if (k < a.nlev) { np_ = ld<T>(a.p, k, c); nt_ = ld<T>(a.t, k, c); ntd_ = ld<T>(a.td, k, c); }
+    // Level loads: when the three views share their strides and a column's byte offset inside a level row fits 32 bits
+    // (the host checks; always so for (lev, y, x) grids), one 32-bit per-lane offset serves all three arrays and the row
+    // base is scalar -- instead of three 64-bit per-lane base addresses held through the loop (5 VGPRs less).
+    const uint32_t voff = (uint32_t)((uint64_t)c * (uint64_t)a.p.cs * sizeof(T));
+    auto load3 = [&](int64_t kk, double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
+        size_t rb = (size_t)kk * (size_t)a.p.ls * sizeof(T);
+        P_ = (double)*(const T *)((const char *)a.p.data + rb + voff);
+        T2_ = (double)*(const T *)((const char *)a.t.data + rb + voff);
+        Td2_ = (double)*(const T *)((const char *)a.td.data + rb + voff);
+    };
+    if (k < a.nlev) load3(k, np_, nt_, ntd_);
     for (; k < a.nlev; ++k) {                                              // phase A
         if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
         double P = np_, T_ = nt_, Td_ = as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
         source(P, T_, Td_);
     }
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
         constexpr bool Q = HUM && !PROFILE;
         double P = np_, T_ = nt_, m_ = Q ? ntd_ : as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
         moist_node(P, log_tab(es, P), T_, m_, Q);
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
@@ -611,6 +622,16 @@ void k_crossing_level(View xv, View av, int64_t nlev, int64_t ncol, double value
         x0 = x1; d0 = d1;
     }
     st(out, sizeof(T) == 8, c, best);
+}
+
+// dense (nlev, ncol) copy of a strided view: the fall-back for inputs whose three views do not share strides (or
+// whose column offsets exceed 32 bits), see CapeArgs::off32
+template <typename T> __global__ __launch_bounds__(256)
+void k_densify(View v, int64_t nlev, int64_t ncol, T *out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nlev * ncol) return;
+    int64_t k = e / ncol, c = e - k * ncol;
+    out[e] = ((const T *)v.data)[k * v.ls + c * v.cs];
 }
 
 // host-side launcher of k_cape_cin<T, pm, profile, MODE, a.hum>, defined in xp_cape_tu.hip -- one translation unit per

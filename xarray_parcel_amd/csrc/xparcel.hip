@@ -226,6 +226,26 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     a->nlev = p->nlev; a->ncol = p->ncol;
     a->depth = parcel->depth;
     a->es_tab = g.es_tab;
+    {   // fast level addressing (xp_kernels.hpp load3): common strides, non-negative, column offsets below 4 GiB
+        bool same = a->p.ls == a->t.ls && a->p.ls == a->td.ls && a->p.cs == a->t.cs && a->p.cs == a->td.cs;
+        bool fits = a->p.cs >= 0 && a->p.ls >= 0 &&
+                    (unsigned long long)a->p.cs * (unsigned long long)(p->ncol > 0 ? p->ncol : 1) * esize(p->dtype) < (1ull << 32);
+        a->off32 = 1;
+        if (!(same && fits)) {                               // rare: densify the three views on the device first
+            size_t n = (size_t)p->nlev * (size_t)p->ncol, bytes = n * esize(p->dtype);
+            xp::View *vs[3] = {&a->p, &a->t, &a->td};
+            for (int i = 0; i < 3 && n; ++i) {
+                void *d = nullptr;
+                HIP_TRY(hipMalloc(&d, bytes));
+                st.scratch.push_back(d);
+                if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_densify<double>), dim3(blocks((int64_t)n)), dim3(256), 0, st.s, *vs[i], p->nlev, p->ncol, (double *)d);
+                else hipLaunchKernelGGL((xp::k_densify<float>), dim3(blocks((int64_t)n)), dim3(256), 0, st.s, *vs[i], p->nlev, p->ncol, (float *)d);
+                vs[i]->data = d; vs[i]->ls = p->ncol; vs[i]->cs = 1;
+            }
+            if ((unsigned long long)(p->ncol > 0 ? p->ncol : 1) * esize(p->dtype) >= (1ull << 32))
+                return fail(XP_E_ARG, "more than 4 GiB per level row");
+        }
+    }
     a->fam_tab = g.fam_tab;
     if (parcel->mode == XP_PARCEL_EXPLICIT) {
         if (!parcel->pressure || !parcel->temperature || !parcel->dewpoint) return fail(XP_E_ARG, "explicit parcel: null arrays");
