@@ -1,7 +1,7 @@
 // xp_kernels.hpp -- HIP kernels of libxparcel: one thread = one column, lanes of a wavefront own
 // x-adjacent columns so every level read is one coalesced 256 B (fp32) / 512 B (fp64) request per
-// array (layout (lev, y, x), col_stride == 1).  No LDS, no MFMA: the path is an elementwise +
-// per-column scan.
+// array (layout (lev, y, x), col_stride == 1).  No MFMA: the path is an elementwise + per-column scan
+// (SURVEY.md 8d); LDS holds the e_s / ln lookup tables and the per-thread slots of the scan (xp_device.hpp).
 #pragma once
 #include "xp_device.hpp"
 
@@ -148,10 +148,12 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
-__global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE || HUM) ? 3 : (PMODE == PM_SURFACE ? 1 : 4))) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
-    // with 32-48 B of scratch, still a net gain); profile output, q input and the family mode stay at 3 waves (168).
+    // with 24 B of scratch or none, still a net gain); profile output and the family mode stay at 3 waves (168).  The
+    // bound only steers the allocator (with q input the surface kernel lands on 126 under "3" and on 129 under "1");
+    // tests/test_kernel_resources.py checks what comes out.
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
