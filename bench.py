@@ -78,6 +78,8 @@ def main():
                          'table = the reference\'s lookup tables (pf.py:525-607), generated on the GPU before the timed region')
     ap.add_argument('--humidity', default='dewpoint', choices=['dewpoint', 'specific'],
                     help="'specific': feed specific humidity and convert on load (XP_HUM_SPECIFIC); not the headline")
+    ap.add_argument('--data', default='hashed', choices=['hashed', 'smooth'],
+                    help="'smooth': spatially correlated columns (sensitivity run; the headline uses SURVEY 8d's hashed columns)")
     ap.add_argument('--nlev', type=int, default=NLEV)
     ap.add_argument('--ny', type=int, default=NY)
     ap.add_argument('--nx', type=int, default=NX)
@@ -119,7 +121,8 @@ def main():
 
     tdt = torch.float64 if a.dtype == 'f64' else torch.float32
     ncol = a.ny * a.nx
-    p, t, td = synth.columns_torch(a.nlev, ncol, dev, seed=20250719, dtype=tdt, col_offset=rank * ncol)
+    p, t, td = synth.columns_torch(a.nlev, ncol, dev, seed=20250719, dtype=tdt, col_offset=rank * ncol,
+                                   smooth=(a.data == 'smooth'), nx=a.nx)
     if a.humidity == 'specific':                                   # q of air with the synthetic dewpoint (exact inversion)
         e = 6.112 * torch.exp(17.67 * (td - 273.15) / (td - 29.65))
         w = 0.6219569100577033 * e / (p - e)
@@ -188,7 +191,7 @@ def main():
             'metric': 'column-profiles/sec for surface_based_cape_cin', 'value': world * ncol * a.steps / dt,
             'unit': 'column-profiles/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': 'synthetic',
+            'dtype': a.dtype, 'data': 'synthetic' if a.data == 'hashed' else 'synthetic (spatially smooth variant, not the headline data)',
             'config': {'workload': f'c2: synthetic {a.nlev}-level x {a.ny} x {a.nx} {a.dtype} soundings per GPU, '
                                    f'surface_based_cape_cin (CAPE/CIN only), exact moist mode ({a.moist}), inputs resident in HBM',
                        'columns_per_gpu': ncol, 'levels': a.nlev,

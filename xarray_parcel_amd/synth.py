@@ -39,6 +39,21 @@ def column_uniforms(ncol, seed, col_offset=0):
     return out
 
 
+def column_uniforms_smooth(ncol, seed, col_offset=0, nx=1024, noise=0.005):
+    """Spatially smooth variant of column_uniforms for sensitivity runs (NOT the headline data): every slot is a
+    low-wavenumber wave over the (y, x) grid of row length nx plus a little hashed noise, so neighbouring columns --
+    the lanes of a wavefront -- resemble each other the way model fields do."""
+    ids = np.arange(ncol, dtype=np.float64) + float(col_offset)
+    x, y = np.mod(ids, nx) / nx, np.floor(ids / nx) / nx
+    h = column_uniforms(ncol, seed, col_offset)
+    rng = np.random.default_rng(seed)
+    out = np.empty((N_UNIFORMS, ncol), dtype=np.float64)
+    for j in range(N_UNIFORMS):
+        fx, fy, ph = rng.uniform(0.2, 0.8), rng.uniform(0.5, 3.0), rng.uniform(0, 2 * np.pi)
+        out[j] = np.clip(0.5 + 0.47 * np.sin(2 * np.pi * (fx * x + fy * y) + ph) + noise * (h[j] - 0.5), 0.0, 1.0 - 1e-12)
+    return out
+
+
 def _fields(u, nlev, xp, k_index, saturate_some):
     """Shared formula; xp is numpy or torch.  u: (N_UNIFORMS, ncol); k_index: (nlev, 1) float."""
     p_sfc = 960.0 + 75.0 * u[0]
@@ -92,7 +107,7 @@ def columns(nlev, ncol, seed=20250718, nan_fraction=0.0, dtype=np.float64, col_o
     return p, t, td
 
 
-def columns_torch(nlev, ncol, device, seed=20250718, dtype=None, col_offset=0, chunk=1 << 20):
+def columns_torch(nlev, ncol, device, seed=20250718, dtype=None, col_offset=0, chunk=1 << 20, smooth=False, nx=1024):
     """Same soundings built directly in device memory (perf runs: no NaNs).  Per-column
     uniforms come from the host hash; the (nlev, ncol) fields are evaluated on the device
     in float64 and cast, chunked so the float64 temporaries stay small."""
@@ -104,7 +119,8 @@ def columns_torch(nlev, ncol, device, seed=20250718, dtype=None, col_offset=0, c
     k = torch.arange(nlev, dtype=torch.float64, device=device)[:, None]
     for c0 in range(0, ncol, chunk):
         c1 = min(ncol, c0 + chunk)
-        u = torch.from_numpy(column_uniforms(c1 - c0, seed, col_offset + c0)).to(device)
+        uf = column_uniforms_smooth(c1 - c0, seed, col_offset + c0, nx) if smooth else column_uniforms(c1 - c0, seed, col_offset + c0)
+        u = torch.from_numpy(uf).to(device)
         pp, tt, dd = _fields(u, nlev, torch, k, False)
         p[:, c0:c1] = pp.to(dtype)
         t[:, c0:c1] = tt.to(dtype)
