@@ -1,0 +1,28 @@
+"""Parity soak: many seeds x level counts x parcels x option sets x dtypes against the C oracle, with the tie
+classification of tests/test_gpu_parity.py.  Prints one line per combination and a summary; exits non-zero on a mismatch."""
+import sys, itertools, time
+sys.path.insert(0, '.')
+import numpy as np
+from oracle import c_oracle as co
+from tests import test_gpu_parity as tp
+from xarray_parcel_amd import numpy_api as xa, synth
+tp.xa = xa
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
+bad = 0; n = 0; t0 = time.time()
+for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100), ('surface', 'most_unstable', 'mixed_layer'),
+                                                         range(len(tp.MODES)), (np.float64, np.float32)):
+    kw = tp.MODES[mode]
+    p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed * 7 + nlev, nan_fraction=0.08, dtype=dtype)
+    got = xa.cape_cin_columns(p, t, td, parcel=parcel, **kw)
+    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4', **kw)
+    n += 1
+    try:
+        tp._compare(got, ref, dtype, 1e-6)
+    except AssertionError as e:
+        bad += 1
+        print('MISMATCH', seed, nlev, parcel, mode, dtype.__name__, str(e)[:300], flush=True)
+    if n % 24 == 0:
+        print('progress', n, 'combos', round(time.time() - t0), 's', flush=True)
+print('SOAK', n, 'combinations x', ncol, 'columns:', bad, 'mismatching combinations')
+sys.exit(1 if bad else 0)

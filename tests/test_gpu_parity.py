@@ -68,7 +68,15 @@ def _saturated_tie_columns(got, ref):
         on_lcl = ((np.abs(np.asarray(got['lfc_pressure'], dtype=np.float64) - lcl) <= 1e-6 * lcl) &
                   (np.abs(ref['lfc_pressure'] - lcl) <= 1e-9 * lcl))
     label_only = tie & on_lcl & ((gi == -2) | (ri == -2))
-    excluded = tie & ~label_only
+    # (c) the same for a DEcreasing crossing that sits on the LCL of a saturated parcel (parcel cooler than the environment
+    #     right above its level): whether it counts as an EL "above the LCL" (pf.py:1151-1155) is again exp(ln p) < p
+    #     in the last bit -- found by scripts/run_gpu_soak.py, one column in 2.3e7.
+    ge, re_ = np.asarray(got['el_index']), ref['el_index']
+    with np.errstate(invalid='ignore'):
+        el_on_lcl = ((np.abs(np.asarray(got['el_pressure'], dtype=np.float64) - lcl) <= 1e-6 * lcl) |
+                     (np.abs(ref['el_pressure'] - lcl) <= 1e-9 * lcl))
+    el_tie = lcl_on_parcel & (ge != re_) & el_on_lcl
+    excluded = (tie & ~label_only) | el_tie
     assert excluded.sum() <= max(2, tie.size // 400), ('too many saturated-parcel sign ties', int(excluded.sum()))
     assert label_only.sum() <= max(4, tie.size // 100), ('too many LCL-label ties', int(label_only.sum()))
     return label_only, excluded

@@ -107,6 +107,14 @@ XP_DEV double theta_e(double p, double t, double td) {
 __device__ __attribute__((noinline)) double sat_vapor_pressure_slow(double t) { return sat_vapor_pressure(t); }
 __device__ __attribute__((noinline)) double exp_slow(double x) { return exp(x); }
 __device__ __attribute__((noinline)) double log_slow(double x) { return log(x); }
+// x of an intersection exactly as the reference spells it (pf.py:1046), two roundings in the numerator (no FMA
+// contraction) and an IEEE division: used where the result decides a "p* < p_lcl" tie
+__device__ __attribute__((noinline)) double crossing_x_ref(double y, double yp, double X, double Xp) {
+#pragma clang fp contract(off)
+    double a = y * Xp;
+    double b = yp * X;
+    return (a - b) / (y - yp);
+}
 
 // ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
 // The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
@@ -585,9 +593,10 @@ struct Scan {
         bool above = xs < x_lcl;                                            // p* < p_lcl
         bool near_lcl = fabs(xs - x_lcl) <= 2e-9;
         if (__builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
-            double q = xs;
+            double q = y;
             asm volatile("" : "+v"(q));
-            double ps = exp_slow(q);
+            xs = crossing_x_ref(q, yp, X, Xp);                              // the tie is decided on the reference's own rounding
+            double ps = exp_slow(xs);
             zlog = log_slow(ps);
             above = ps < p_lcl;
         }
