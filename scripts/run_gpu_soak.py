@@ -9,13 +9,25 @@ from xarray_parcel_amd import numpy_api as xa, synth
 tp.xa = xa
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
+variant = sys.argv[3] if len(sys.argv) > 3 else 'exact'        # exact | family | specific (q input, fused conversion)
+if variant == 'family':
+    xa.set_family_table(co.family_table())                     # both sides interpolate the oracle's table
+from oracle import thermo as th
 bad = 0; n = 0; t0 = time.time()
 for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100), ('surface', 'most_unstable', 'mixed_layer'),
                                                          range(len(tp.MODES)), (np.float64, np.float32)):
     kw = tp.MODES[mode]
     p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed * 7 + nlev, nan_fraction=0.08, dtype=dtype)
-    got = xa.cape_cin_columns(p, t, td, parcel=parcel, **kw)
-    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4', **kw)
+    if variant == 'specific':
+        e = th.saturation_vapor_pressure(td.astype(np.float64)); w = th.EPSILON * e / (p - e)
+        q = (w / (1.0 + w)).astype(dtype)
+        with np.errstate(all='ignore'):
+            td_ref = th.dewpoint_from_specific_humidity(p.astype(np.float64), t.astype(np.float64), q.astype(np.float64))
+        got = xa.cape_cin_columns(p, t, q, parcel=parcel, humidity='specific', **kw)
+        ref = co.cape_cin_grid(p.astype(np.float64), t.astype(np.float64), td_ref, parcel=parcel, moist='rk4', **kw)
+    else:
+        got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, **kw)
+        ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if variant == 'exact' else variant, **kw)
     n += 1
     try:
         tp._compare(got, ref, dtype, 1e-6)
