@@ -87,12 +87,13 @@ struct Stager {
     std::vector<Back> back;
     bool any_host = false;
     explicit Stager(void *stream) : s((hipStream_t)stream) {}
-    ~Stager() { for (void *p : scratch) (void)hipFree(p); }
+    // stream-ordered allocations: a host-array call stages ~25 buffers, and hipMalloc / hipFree would each synchronise
+    ~Stager() { for (void *p : scratch) (void)hipFreeAsync(p, s); }
     int in(const void *p, size_t bytes, int mem, const void **out) {
         *out = p;
         if (p == nullptr || mem == XP_MEM_DEVICE) return 0;
         void *d = nullptr;
-        HIP_TRY(hipMalloc(&d, bytes ? bytes : 1));
+        HIP_TRY(hipMallocAsync(&d, bytes ? bytes : 1, s));
         scratch.push_back(d);
         HIP_TRY(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, s));
         any_host = true;
@@ -103,7 +104,7 @@ struct Stager {
         *dev = p;
         if (p == nullptr || mem == XP_MEM_DEVICE) return 0;
         void *d = nullptr;
-        HIP_TRY(hipMalloc(&d, bytes ? bytes : 1));
+        HIP_TRY(hipMallocAsync(&d, bytes ? bytes : 1, s));
         scratch.push_back(d);
         back.push_back({p, d, bytes});
         any_host = true;
@@ -236,7 +237,7 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
             xp::View *vs[3] = {&a->p, &a->t, &a->td};
             for (int i = 0; i < 3 && n; ++i) {
                 void *d = nullptr;
-                HIP_TRY(hipMalloc(&d, bytes));
+                HIP_TRY(hipMallocAsync(&d, bytes, st.s));
                 st.scratch.push_back(d);
                 if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_densify<double>), dim3(blocks((int64_t)n)), dim3(256), 0, st.s, *vs[i], p->nlev, p->ncol, (double *)d);
                 else hipLaunchKernelGGL((xp::k_densify<float>), dim3(blocks((int64_t)n)), dim3(256), 0, st.s, *vs[i], p->nlev, p->ncol, (float *)d);
