@@ -643,4 +643,96 @@ def surface_cape_vector(pressure, temperature, specific_humidity, **kwargs):
     return surface_based_cape_cin(pressure, temperature, td, **kwargs)
 
 
+
+# -- product bundle (pf.py:1951-2100, 2216-2407), one column at a time -------------------------------------------------
+def wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, height, shear_height=6000):
+    """pf.py:2216-2259."""
+    hu = linear_interp(wind_u, height, shear_height)
+    hv = linear_interp(wind_v, height, shear_height)
+    su, sv = hu - surface_wind_u, hv - surface_wind_v
+    with np.errstate(invalid='ignore'):
+        return {'shear_u': su, 'shear_v': sv, 'shear_magnitude': np.sqrt(su ** 2 + sv ** 2),
+                'positive_shear': bool(np.sqrt(hu ** 2 + hv ** 2) > np.sqrt(surface_wind_u ** 2 + surface_wind_v ** 2))}
+
+
+def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh):
+    """pf.py:2261-2306 on scalars or arrays."""
+    with np.errstate(invalid='ignore'):
+        mixing_ratio = np.asarray(mixing_ratio, dtype=np.float64) * 1e3
+        lapse = -np.asarray(lapse, dtype=np.float64)
+        temp_500 = np.asarray(temp_500, dtype=np.float64) - 273.15
+        shear = np.asarray(shear, dtype=np.float64)
+        mucape = np.asarray(mucape, dtype=np.float64)
+        flh = np.asarray(flh, dtype=np.float64)
+        shear = _where(shear <= 27, _where(shear >= 7, shear))
+        mixing_ratio = _where(mixing_ratio <= 13.6, _where(mixing_ratio >= 11, mixing_ratio))
+        temp_500 = np.where(temp_500 <= -5.5, temp_500, -5.5)
+        ship = mucape * mixing_ratio * lapse * -temp_500 * shear / 42000000
+        ship = np.where(mucape >= 1300, ship, ship * (mucape / 1300))
+        ship = np.where(lapse >= 5.8, ship, ship * (lapse / 5.8))
+        ship = np.where(flh >= 2400, ship, ship * (flh / 2400))
+    return ship
+
+
+def conv_properties(pressure, temperature, specific_humidity, height_asl, surface_wind_u, surface_wind_v, wind_u, wind_v,
+                    wind_height_above_surface, ignore_nans=False, moist=None):
+    """pf.py:1951-2100 for ONE column; returns a dict of scalars with the reference's variable names."""
+    p, t, q = _f(pressure), _f(temperature), _f(specific_humidity)
+    with np.errstate(all='ignore'):
+        td = th.dewpoint_from_specific_humidity(p, t, q)
+    valid = not (np.isnan(td).any() or np.isnan(p).any() or np.isnan(t).any() or np.isnan(q).any())
+    if not ignore_nans and not valid:                     # blanked at the end anyway (pf.py:2097-2098): skip the work
+        names = [f'{a}_{b}' for a in ('mu', 'mixed_100', 'mixed_50') for b in ('cape', 'cin', 'lifted_index', 'dci')]
+        names += ['mu_mixing_ratio', 'lapse_rate_700_500', 'temp_500', 'freezing_level', 'melting_level', 'shear_u', 'shear_v',
+                  'shear_magnitude']
+        return dict({k: np.nan for k in names}, positive_shear=False)
+    out = {}
+    cc, prof, parcel = most_unstable_cape_cin(p, t, td, depth=250, moist=moist)
+    out['mu_cape'], out['mu_cin'] = cc['cape'], cc['cin']
+    w = th.saturation_mixing_ratio(parcel['pressure'], parcel['dewpoint'])     # specific_humidity_from_dewpoint ...
+    qs = w / (1.0 + w)
+    out['mu_mixing_ratio'] = qs / (1.0 - qs)                                    # ... mixing_ratio_from_specific_humidity
+    out['mu_lifted_index'] = lifted_index(prof)
+    for depth in (100, 50):
+        cc, prof, _ = mixed_layer_cape_cin(p, t, td, depth=depth, moist=moist)
+        out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = cc['cape'], cc['cin']
+        out[f'mixed_{depth}_lifted_index'] = lifted_index(prof)
+    for pre in ('mu', 'mixed_100', 'mixed_50'):
+        out[pre + '_dci'] = deep_convective_index(p, t, td, out[pre + '_lifted_index'])
+    out['lapse_rate_700_500'] = lapse_rate(p, t, height_asl)
+    out['temp_500'] = isobar_temperature(p, t, 500.0)
+    out['freezing_level'] = freezing_level_height(t, height_asl)
+    out['melting_level'] = melting_level_height(p, t, td, height_asl)[0]
+    out.update(wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, wind_height_above_surface))
+    return out
+
+
+def storm_proxies(dat):
+    """pf.py:2323-2407 on a dict of arrays (the output of conv_properties for many columns)."""
+    d = {k: np.asarray(v, dtype=np.float64) if k != 'positive_shear' else np.asarray(v, dtype=bool) for k, v in dat.items()}
+    with np.errstate(invalid='ignore'):
+        s06 = d['shear_magnitude']
+        c100 = _where(d['mixed_100_cape'] >= 0, d['mixed_100_cape'])
+        c50 = _where(d['mixed_50_cape'] >= 0, d['mixed_50_cape'])
+        mucape = _where(d['mu_cape'] >= 0, d['mu_cape'])
+        out = {}
+        out['proxy_Craven2004'] = (c100 * s06) >= 20000
+        out['proxy_Kunz2007'] = np.logical_or(d['mixed_100_lifted_index'] <= -2.07,
+                                              np.logical_or(mucape >= 1474, d['mixed_100_dci'] >= 25.7))
+        tr = np.logical_and(c100 * s06 >= 10000, c100 >= 100)
+        tr = np.logical_and(tr, s06 >= 5)
+        out['proxy_Trapp2007'] = np.logical_and(tr, d['positive_shear'])
+        out['proxy_Marsh2009'] = (c100 * s06) >= 10000
+        out['proxy_Allen2011'] = c50 * s06 ** 1.67 >= 25000
+        al = np.logical_and(out['proxy_Allen2011'], d['mixed_50_cin'] > -25)
+        al = np.logical_and(al, s06 > 7.5)
+        out['proxy_Allen2014'] = np.logical_and(al, d['lapse_rate_700_500'] < -6.5)
+        out['proxy_Eccel2012'] = np.logical_and(c100 * s06 > 10000, d['mixed_100_cin'] > -50)
+        mo = np.logical_or(d['mixed_100_lifted_index'] <= -1.6, c100 >= 439)
+        out['proxy_Mohr2013'] = np.logical_or(mo, d['mixed_100_dci'] >= 26.4)
+        out['ship'] = significant_hail_parameter(mucape, d['mu_mixing_ratio'], d['lapse_rate_700_500'], d['temp_500'], s06,
+                                                 d['freezing_level'])
+        out['proxy_SHIP_0.1'] = out['ship'] > 0.1
+    return out
+
 warnings.filterwarnings('ignore', message='Mean of empty slice')

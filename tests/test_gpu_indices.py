@@ -159,3 +159,67 @@ def test_xarray_mirrors_and_harness(xa):
     assert np.nanmax(np.abs(a['cape'].values.ravel() - ref['cape'])) <= 1e-6
     bench = pt.benchmark_cape(dat, points=[2, 4, 9])
     assert list(bench['xr_load'].coords['pts']) == [4, 16, 81] and np.all(bench['device'].values > 0)
+
+
+def _bundle_inputs(nlev=40, ncol=48, seed=51, nan_fraction=0.06):
+    p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed, nan_fraction=nan_fraction, dtype=np.float64)
+    q = _specific_humidity(p, td)
+    z = _heights(p)
+    rng = np.random.default_rng(seed)
+    nw = 12
+    wh = np.linspace(50.0, 9000.0, nw)[:, None] + rng.uniform(0, 40, (1, ncol))        # wind heights above the surface [m]
+    wu = 5.0 + wh * 2.5e-3 + rng.normal(0, 3, (nw, ncol))
+    wv = -2.0 + wh * 1.0e-3 + rng.normal(0, 3, (nw, ncol))
+    return {'pressure': p, 'temperature': t, 'specific_humidity': q, 'height_asl': z, 'wind_u': wu, 'wind_v': wv,
+            'wind_height_above_surface': wh, 'surface_wind_u': rng.normal(2, 2, ncol), 'surface_wind_v': rng.normal(0, 2, ncol)}
+
+
+def test_conv_properties_and_storm_proxies_vs_oracle(xa):
+    """The reference's product bundle (pf.py:1951 conv_properties, pf.py:2323 storm_proxies) as compositions of the
+    device calls, against the same compositions of the oracle, column by column."""
+    d = _bundle_inputs()
+    got = xa.conv_properties(d)
+    ncol = d['pressure'].shape[1]
+    po.set_moist_lapse('rk4')
+    try:
+        with np.errstate(all='ignore'):
+            ref = [po.conv_properties(*(d[k][:, c] for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')),
+                                      d['surface_wind_u'][c], d['surface_wind_v'][c], d['wind_u'][:, c], d['wind_v'][:, c],
+                                      d['wind_height_above_surface'][:, c]) for c in range(ncol)]
+    finally:
+        po.set_moist_lapse('ode')
+    tol = {'cape': 1e-6, 'cin': 1e-6}
+    for k in got:
+        g = np.asarray(got[k])
+        r = np.array([x[k] for x in ref])
+        if k == 'positive_shear':
+            assert np.array_equal(g.astype(bool), r.astype(bool)), k
+            continue
+        assert np.array_equal(np.isnan(g), np.isnan(r)), (k, np.nonzero(np.isnan(g) != np.isnan(r))[0][:5])
+        ok = ~np.isnan(r)
+        err = np.abs(g[ok] - r[ok])
+        lim = tol.get(k.split('_')[-1], 1e-8) * np.maximum(1.0, np.abs(r[ok]))
+        assert np.all(err <= lim), (k, float(err.max()))
+    assert np.isnan(np.asarray(got['mu_cape'])).sum() >= 1            # NaN columns are blanked (pf.py:2097-2098)
+    gp, rp = xa.storm_proxies(got), po.storm_proxies({k: np.array([x[k] for x in ref]) for k in ref[0]})
+    for k in rp:
+        if k == 'ship':
+            a, b = np.asarray(gp[k]), rp[k]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b), initial=0.0) <= 1e-9
+        else:
+            assert np.array_equal(np.asarray(gp[k]).astype(bool), rp[k].astype(bool)), k
+    # the xarray-facing mirror: same numbers, reference names / attrs
+    from xarray_parcel_amd import parcel_functions as pf
+    from xarray_parcel_amd._xr import DataArray, Dataset
+    nlev, nw = d['pressure'].shape[0], d['wind_u'].shape[0]
+    ds = Dataset({k: DataArray(d[k], dims=('model_level_number', 'point')) for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')})
+    for k in ('wind_u', 'wind_v', 'wind_height_above_surface'):
+        ds[k] = DataArray(d[k], dims=('wind_level', 'point'))
+    for k in ('surface_wind_u', 'surface_wind_v'):
+        ds[k] = DataArray(d[k], dims=('point',))
+    props = pf.conv_properties(ds)
+    assert props['mixed_100_dci'].attrs['units'] == 'C' and props['mu_cape'].dims == ('point',)
+    assert np.allclose(props['mu_cape'].values, np.asarray(got['mu_cape']), equal_nan=True)
+    prox = pf.storm_proxies(props)
+    assert prox['proxy_Kunz2007'].attrs['long_name'] == 'Proxy Kunz 2007'
+    assert np.array_equal(prox['proxy_SHIP_0.1'].values.astype(bool), np.asarray(gp['proxy_SHIP_0.1']).astype(bool))

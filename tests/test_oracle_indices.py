@@ -56,3 +56,22 @@ def test_dewpoint_from_specific_humidity_chain():
     es = th.saturation_vapor_pressure(t)
     ws = th.EPSILON * es / (p - es)
     assert abs(th.dewpoint_from_specific_humidity(p, t, ws / (1 + ws)) - t) < 1e-10
+
+
+def test_wind_shear_and_ship():
+    h = np.array([100.0, 3000.0, 6000.0, 9000.0])
+    u = np.array([2.0, 10.0, 20.0, 30.0])
+    v = np.array([0.0, 0.0, 5.0, 5.0])
+    ws = po.wind_shear(1.0, -1.0, u, v, h)
+    assert ws['shear_u'] == 19.0 and ws['shear_v'] == 6.0 and ws['positive_shear']
+    assert abs(ws['shear_magnitude'] - np.hypot(19.0, 6.0)) < 1e-12
+    # SHIP: all thresholds satisfied -> plain product; a low freezing level scales it down
+    ship = po.significant_hail_parameter(2000.0, 0.012, -7.0, 258.15, 20.0, 3000.0)
+    assert abs(ship - 2000.0 * 12.0 * 7.0 * 15.0 * 20.0 / 42000000) < 1e-12
+    assert abs(po.significant_hail_parameter(2000.0, 0.012, -7.0, 258.15, 20.0, 1200.0) - 0.5 * ship) < 1e-12
+    assert np.isnan(po.significant_hail_parameter(2000.0, 0.012, -7.0, 258.15, 30.0, 3000.0))   # shear outside 7..27
+    prox = po.storm_proxies({'shear_magnitude': [20.0], 'mixed_100_cape': [1200.0], 'mixed_50_cape': [1500.0], 'mu_cape': [2000.0],
+                             'mixed_100_lifted_index': [-3.0], 'mixed_100_dci': [20.0], 'positive_shear': [True],
+                             'mixed_50_cin': [-10.0], 'lapse_rate_700_500': [-7.0], 'mixed_100_cin': [-20.0],
+                             'mu_mixing_ratio': [0.012], 'temp_500': [258.15], 'freezing_level': [3000.0]})
+    assert all(bool(prox[k][0]) for k in prox if k != 'ship')

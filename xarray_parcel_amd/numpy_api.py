@@ -17,6 +17,8 @@ import numpy as np
 
 from . import _lib as L
 
+L_EPS = 0.6219569100577033        # Mw / Md (metpy.constants, 1.4.1)
+
 try:  # torch is plumbing (device memory, streams); the API also works without it on host arrays
     import torch
 except Exception:  # pragma: no cover
@@ -477,6 +479,112 @@ def lifted_index(profile):
     env = interp_level(profile['pressure'], profile['environment_temperature'], 500.0, log=True)
     par = interp_level(profile['pressure'], profile['temperature'], 500.0, log=True)
     return env - par
+
+
+# ---- product bundle (pf.py:1951-2100, 2216-2407): compositions of the calls above + array arithmetic ---------------
+def _ns(x):
+    """numpy-or-torch namespace shim for the few element-wise helpers the bundle needs."""
+    if _is_torch(x):
+        return torch
+    return np
+
+
+def _where(c, a, b):
+    if _is_torch(c) or _is_torch(a) or _is_torch(b):
+        dev = next(v.device for v in (c, a, b) if _is_torch(v))
+        a = a if _is_torch(a) else torch.as_tensor(a, device=dev, dtype=torch.float64)
+        b = b if _is_torch(b) else torch.as_tensor(b, device=dev, dtype=a.dtype)
+        return torch.where(c, a, b.to(a.dtype))
+    return np.where(c, a, b)
+
+
+def wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, height, shear_height=6000):
+    """pf.py:2216: wind at `shear_height` (linear interpolation in height) minus the surface wind."""
+    hi_u = interp_level(height, wind_u, float(shear_height), log=False)
+    hi_v = interp_level(height, wind_v, float(shear_height), log=False)
+    shear_u, shear_v = hi_u - surface_wind_u, hi_v - surface_wind_v
+    xp = _ns(shear_u)
+    return {'shear_u': shear_u, 'shear_v': shear_v, 'shear_magnitude': xp.sqrt(shear_u ** 2 + shear_v ** 2),
+            'positive_shear': xp.sqrt(hi_u ** 2 + hi_v ** 2) > xp.sqrt(surface_wind_u ** 2 + surface_wind_v ** 2)}
+
+
+def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh):
+    """pf.py:2261 (SPC SHIP): array arithmetic with the reference's validity windows."""
+    nan = float('nan')
+    mixing_ratio = mixing_ratio * 1e3
+    lapse = -lapse
+    temp_500 = temp_500 - 273.15
+    shear = _where((shear >= 7) & (shear <= 27), shear, nan)
+    mixing_ratio = _where((mixing_ratio >= 11) & (mixing_ratio <= 13.6), mixing_ratio, nan)
+    temp_500 = _where(temp_500 <= -5.5, temp_500, -5.5)
+    ship = mucape * mixing_ratio * lapse * -temp_500 * shear / 42000000
+    ship = _where(mucape >= 1300, ship, ship * (mucape / 1300))
+    ship = _where(lapse >= 5.8, ship, ship * (lapse / 5.8))
+    ship = _where(flh >= 2400, ship, ship * (flh / 2400))
+    return ship
+
+
+def conv_properties(dat, ignore_nans=False):
+    """pf.py:1951: the reference's convective-property bundle for a grid.  `dat`: mapping with pressure [hPa],
+    temperature [K], specific_humidity [kg/kg], height_asl [m] (nlev, ...), wind_u, wind_v,
+    wind_height_above_surface (nwind, ...), surface_wind_u, surface_wind_v (...).  Returns a dict of per-column
+    arrays with the reference's variable names."""
+    p, t, q = dat['pressure'], dat['temperature'], dat['specific_humidity']
+    td = dewpoint_from_specific_humidity(p, t, q)
+    xp = _ns(td)
+    to = (lambda a: torch.as_tensor(np.asarray(a), device=td.device) if not _is_torch(a) else a) if _is_torch(td) else np.asarray
+    p, t, q, z = to(p), to(t), to(q), to(dat['height_asl'])
+    valid = ~(xp.isnan(td).any(0) | xp.isnan(p).any(0) | xp.isnan(t).any(0) | xp.isnan(q).any(0))
+    out = {}
+    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, want_profile=True)
+    out['mu_cape'], out['mu_cin'] = mu['cape'], mu['cin']
+    e = 6.112 * xp.exp(17.67 * (mu['parcel_dewpoint'] - 273.15) / (mu['parcel_dewpoint'] - 29.65))
+    w = L_EPS * e / (mu['parcel_pressure'] - e)                       # specific_humidity_from_dewpoint -> mixing ratio
+    qs = w / (1.0 + w)
+    out['mu_mixing_ratio'] = qs / (1.0 - qs)
+    out['mu_lifted_index'] = lifted_index(mu['profile'])
+    for depth in (100, 50):
+        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, want_profile=True)
+        out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
+        out[f'mixed_{depth}_lifted_index'] = lifted_index(ml['profile'])
+    for pre in ('mu', 'mixed_100', 'mixed_50'):
+        out[pre + '_dci'] = deep_convective_index(p, t, td, out[pre + '_lifted_index'])
+    out['lapse_rate_700_500'] = lapse_rate(p, t, z)
+    out['temp_500'] = isobar_temperature(p, t, 500.0)
+    out['freezing_level'] = freezing_level_height(t, z)
+    out['melting_level'], _ = melting_level_height(p, t, td, z)
+    out.update(wind_shear(to(dat['surface_wind_u']), to(dat['surface_wind_v']), to(dat['wind_u']), to(dat['wind_v']),
+                          to(dat['wind_height_above_surface'])))
+    if not ignore_nans:
+        for k in out:
+            if k != 'positive_shear':
+                out[k] = _where(valid, out[k], float('nan'))
+            else:
+                out[k] = out[k] & valid          # xarray's where() turns a masked boolean into NaN; here: False
+    return out
+
+
+def storm_proxies(dat):
+    """pf.py:2323: hail / storm proxies (booleans) and SHIP from the output of conv_properties()."""
+    nan = float('nan')
+    s06 = dat['shear_magnitude']
+    c100 = _where(dat['mixed_100_cape'] >= 0, dat['mixed_100_cape'], nan)
+    c50 = _where(dat['mixed_50_cape'] >= 0, dat['mixed_50_cape'], nan)
+    mucape = _where(dat['mu_cape'] >= 0, dat['mu_cape'], nan)
+    out = {}
+    out['proxy_Craven2004'] = (c100 * s06) >= 20000
+    out['proxy_Kunz2007'] = (dat['mixed_100_lifted_index'] <= -2.07) | (mucape >= 1474) | (dat['mixed_100_dci'] >= 25.7)
+    out['proxy_Trapp2007'] = ((c100 * s06 >= 10000) & (c100 >= 100) & (s06 >= 5)) & dat['positive_shear']
+    out['proxy_Marsh2009'] = (c100 * s06) >= 10000
+    out['proxy_Allen2011'] = c50 * s06 ** 1.67 >= 25000
+    out['proxy_Allen2014'] = (out['proxy_Allen2011'] & (dat['mixed_50_cin'] > -25) & (s06 > 7.5) &
+                              (dat['lapse_rate_700_500'] < -6.5))
+    out['proxy_Eccel2012'] = (c100 * s06 > 10000) & (dat['mixed_100_cin'] > -50)
+    out['proxy_Mohr2013'] = (dat['mixed_100_lifted_index'] <= -1.6) | (c100 >= 439) | (dat['mixed_100_dci'] >= 26.4)
+    out['ship'] = significant_hail_parameter(mucape, dat['mu_mixing_ratio'], dat['lapse_rate_700_500'], dat['temp_500'],
+                                             s06, dat['freezing_level'])
+    out['proxy_SHIP_0.1'] = out['ship'] > 0.1
+    return out
 
 
 def family_table():

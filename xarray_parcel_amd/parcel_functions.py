@@ -419,6 +419,92 @@ def dewpoint_from_specific_humidity(pressure, temperature, specific_humidity, ve
     return _vert(out, vert_dim, vc, dims, coords, name='dewpoint', attrs=attrs)
 
 
+# -- product bundle (pf.py:1951-2100, 2216-2407) ------------------------------------------------------------------------
+def wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, height, shear_height=6000, vert_dim=VERT):
+    """pf.py:2216: Dataset with shear_u, shear_v, shear_magnitude [m/s] and positive_shear."""
+    h, dims, coords, _ = _split(height, vert_dim)
+    r = _api.wind_shear(_split(surface_wind_u, vert_dim)[0], _split(surface_wind_v, vert_dim)[0],
+                        _split(wind_u, vert_dim)[0], _split(wind_v, vert_dim)[0], h, shear_height=shear_height)
+    names = {'shear_u': f'Surface to {shear_height} m wind shear, U component.',
+             'shear_v': f'Surface to {shear_height} m wind shear, V component.',
+             'shear_magnitude': f'Surface to {shear_height} m bulk wind shear.',
+             'positive_shear': f'True if {shear_height} wind > surface wind.'}
+    out = Dataset()
+    for k, ln in names.items():
+        attrs = {'long_name': ln}
+        if k != 'positive_shear':
+            attrs['units'] = 'm s$^{-1}$'
+        out[k] = _horiz(_np(r[k]), dims, coords, attrs=attrs, name=k)
+    return out
+
+
+def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh):
+    """pf.py:2261 (SHIP)."""
+    vals = [np.asarray(getattr(x, 'values', x), dtype=np.float64) for x in (mucape, mixing_ratio, lapse, temp_500, shear, flh)]
+    ship = _api.significant_hail_parameter(*vals)
+    ref = mucape if isinstance(mucape, DataArray) else None
+    return DataArray(ship, dims=ref.dims if ref is not None else None, coords=ref.coords if ref is not None else None,
+                     attrs={'long_name': 'Significant hail parameter', 'units': 'J kg$^{-2}$ g K$^2$ km$^{-1}$ m s$^{-1}$'})
+
+
+def valid_data(dat, vert_dim):
+    """pf.py:2308."""
+    vc = np.asarray(dat[vert_dim].values if hasattr(dat[vert_dim], 'values') else dat[vert_dim])
+    assert np.all(np.abs(np.diff(vc)) == 1), 'Index increments must all be 1.'
+    p, _, _, _ = _split(dat['pressure'], vert_dim)
+    assert np.nanmax(np.diff(p, axis=0)) < 0, 'Pressures must decrease with increasing level number.'
+    return True
+
+
+_BUNDLE_ATTRS = {
+    'mu_mixing_ratio': {'long_name': 'Mixing ratio', 'description': 'Mixing ratio of most unstable parcel'},
+    'lapse_rate_700_500': {'long_name': 'Lapse rate', 'description': '700-500 hPa lapse rate', 'units': 'K km$^{-1}$'},
+    'temp_500': {'description': 'Temperature at 500 hPa.', 'long_name': 'Isobar temperature', 'units': 'K'},
+    'freezing_level': {'long_name': 'Freezing-level height', 'units': 'm',
+                       'description': 'Height of zero degree dry-bulb temperature isotherm.'},
+    'melting_level': {'long_name': 'Melting-level height', 'units': 'm',
+                      'description': 'Height of zero degree wet-bulb temperature isotherm.'},
+}
+
+
+def conv_properties(dat, vert_dim=VERT, ignore_nans=False):
+    """pf.py:1951: the convective-property bundle.  `dat` holds pressure, temperature, specific_humidity, height_asl on
+    `vert_dim`, wind_u, wind_v, wind_height_above_surface on their own vertical, surface_wind_u, surface_wind_v."""
+    p, dims, coords, _ = _split(dat['pressure'], vert_dim)
+    wdim = [d for d in dat['wind_u'].dims if d not in dims][0]
+    arrs = {k: _split(dat[k], vert_dim)[0] for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')}
+    arrs.update({k: _split(dat[k], wdim)[0] for k in ('wind_u', 'wind_v', 'wind_height_above_surface')})
+    arrs.update({k: _split(dat[k], vert_dim)[0] for k in ('surface_wind_u', 'surface_wind_v')})
+    r = _api.conv_properties(arrs, ignore_nans=ignore_nans)
+    out = Dataset()
+    for k, v in r.items():
+        attrs = dict(_BUNDLE_ATTRS.get(k, {}))
+        for base in ('cape', 'cin'):
+            if k.endswith('_' + base):
+                attrs = dict(_ATTRS[base])
+        if k.endswith('_lifted_index'):
+            attrs = {'long_name': 'Lifted index', 'units': 'K'}
+        if k.endswith('_dci'):
+            attrs = {'long_name': 'Deep convective index', 'units': 'C'}
+        out[k] = _horiz(_np(v), dims, coords, attrs=attrs, name=k)
+    return out
+
+
+def storm_proxies(dat):
+    """pf.py:2323: proxies (booleans) and SHIP from the Dataset returned by conv_properties()."""
+    ref = dat['mu_cape']
+    r = _api.storm_proxies({k: np.asarray(dat[k].values) for k in dat.keys()})
+    labels = {'proxy_Craven2004': 'Craven 2004', 'proxy_Kunz2007': 'Kunz 2007', 'proxy_Trapp2007': 'Trapp 2007',
+              'proxy_Marsh2009': 'Marsh 2009', 'proxy_Allen2011': 'Allen 2011', 'proxy_Allen2014': 'Allen 2014',
+              'proxy_Eccel2012': 'Eccel 2012', 'proxy_Mohr2013': 'Mohr 2013', 'proxy_SHIP_0.1': 'SHIP > 0.1'}
+    out = Dataset()
+    for k, v in r.items():
+        attrs = {'long_name': 'Proxy ' + labels[k]} if k in labels else {'long_name': 'Significant hail parameter (SHIP)',
+                                                                         'units': 'J kg$^{-2}$ g K$^2$ km$^{-1}$ m s$^{-1}$'}
+        out[k] = DataArray(np.asarray(v), dims=ref.dims, coords=ref.coords, attrs=attrs, name=k)
+    return out
+
+
 # -- tables (pf.py:39-61) ------------------------------------------------------------------------------
 def load_moist_adiabat_lookups(**kwargs):
     """pf.py:39: make the reference-format lookup tables available to moist='table' calls."""
