@@ -9,9 +9,15 @@ from xarray_parcel_amd import numpy_api as xa, synth
 tp.xa = xa
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
-variant = sys.argv[3] if len(sys.argv) > 3 else 'exact'        # exact | family | specific (q input, fused conversion)
+variant = sys.argv[3] if len(sys.argv) > 3 else 'exact'        # exact | family | table | specific (q input, fused conversion)
 if variant == 'family':
     xa.set_family_table(co.family_table())                     # both sides interpolate the oracle's table
+if variant == 'table':
+    from oracle import tables as otb
+    from xarray_parcel_amd import adiabat_tables
+    tab = otb.get_tables()
+    co.set_tables(tab)
+    adiabat_tables.set_tables(tab.index, tab.adiabats)         # both sides look up the same arrays
 from oracle import thermo as th
 bad = 0; n = 0; t0 = time.time()
 for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100), ('surface', 'most_unstable', 'mixed_layer'),
