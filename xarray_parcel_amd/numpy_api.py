@@ -529,6 +529,10 @@ def conv_properties(dat, ignore_nans=False):
     temperature [K], specific_humidity [kg/kg], height_asl [m] (nlev, ...), wind_u, wind_v,
     wind_height_above_surface (nwind, ...), surface_wind_u, surface_wind_v (...).  Returns a dict of per-column
     arrays with the reference's variable names."""
+    host_in = not any(_is_torch(v) for v in dat.values())
+    if host_in and torch is not None and torch.cuda.is_available():
+        # one upload; the ~25 kernel launches of the bundle then work on device-resident data
+        dat = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).cuda() for k, v in dat.items()}
     p, t, q = dat['pressure'], dat['temperature'], dat['specific_humidity']
     td = dewpoint_from_specific_humidity(p, t, q)
     xp = _ns(td)
@@ -561,6 +565,8 @@ def conv_properties(dat, ignore_nans=False):
                 out[k] = _where(valid, out[k], float('nan'))
             else:
                 out[k] = out[k] & valid          # xarray's where() turns a masked boolean into NaN; here: False
+    if host_in:
+        out = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in out.items()}
     return out
 
 
