@@ -47,6 +47,21 @@ def measured_traffic(nlev, ny, nx, dtype):
         return None
 
 
+def measured_valu_busy(nlev, ny, nx, dtype):
+    """Fraction of SIMD cycles spent issuing VALU instructions, from the same committed PMC pass
+    (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)): the kernel is fp64-VALU-bound, so this, not the
+    HBM fraction, says how close it runs to the machine.  None for any other shape."""
+    import glob
+    if (nlev, ny, nx, dtype) != (NLEV, NY, NX, 'f64'):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+    try:
+        d = json.load(open(files[-1]))['per_launch_mean']
+        return float(d['SQ_ACTIVE_INST_VALU'] * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0))
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed, nlev, sample_cols):
     import numpy as np
     from oracle import c_oracle
@@ -201,7 +216,8 @@ def main():
                          'kernel': 'xp::k_cape_cin<%s, 0, false, %d, %s>' % ('double' if a.dtype == 'f64' else 'float',
                                                                             {'exact': 0, 'table': 1, 'family': 2}[a.moist],
                                                                             'true' if a.humidity == 'specific' else 'false'),
-                         'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch},
+                         'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch,
+                         'valu_busy': measured_valu_busy(a.nlev, a.ny, a.nx, a.dtype)},
             'check': {'max_cape': float(last['cape'].max()), 'min_cin': float(last['cin'].min())},
         }
         if not a.no_cpu and world == 1:
