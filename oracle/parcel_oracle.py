@@ -707,6 +707,21 @@ def conv_properties(pressure, temperature, specific_humidity, height_asl, surfac
     return out
 
 
+def min_conv_properties(pressure, temperature, specific_humidity, height_asl, surface_wind_u, surface_wind_v, wind_u, wind_v,
+                        wind_height_above_surface, moist=None):
+    """pf.py:1873-1949 for ONE column."""
+    p, t, q = _f(pressure), _f(temperature), _f(specific_humidity)
+    with np.errstate(all='ignore'):
+        td = th.dewpoint_from_specific_humidity(p, t, q)
+    cc, prof, _ = mixed_layer_cape_cin(p, t, td, depth=100, moist=moist)
+    out = {'mixed_100_cape': cc['cape'], 'mixed_100_cin': cc['cin'], 'mixed_100_lifted_index': lifted_index(prof),
+           'lapse_rate_700_500': lapse_rate(p, t, height_asl), 'temp_500': isobar_temperature(p, t, 500.0),
+           'freezing_level': freezing_level_height(t, height_asl),
+           'melting_level': melting_level_height(p, t, td, height_asl)[0]}
+    out.update(wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, wind_height_above_surface))
+    return out
+
+
 def storm_proxies(dat):
     """pf.py:2323-2407 on a dict of arrays (the output of conv_properties for many columns)."""
     d = {k: np.asarray(v, dtype=np.float64) if k != 'positive_shear' else np.asarray(v, dtype=bool) for k, v in dat.items()}

@@ -208,6 +208,22 @@ def test_conv_properties_and_storm_proxies_vs_oracle(xa):
             assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b), initial=0.0) <= 1e-9
         else:
             assert np.array_equal(np.asarray(gp[k]).astype(bool), rp[k].astype(bool)), k
+    # the minimal bundle (pf.py:1873) on the NaN-free columns
+    clean = np.nonzero(~np.isnan(np.asarray(got['mu_cape'])))[0][:12]
+    dm = {k: (v[..., clean] if np.ndim(v) else v) for k, v in d.items()}
+    gm = xa.min_conv_properties(dm)
+    po.set_moist_lapse('rk4')
+    try:
+        with np.errstate(all='ignore'):
+            for i, c in enumerate(clean):
+                rm = po.min_conv_properties(*(d[k][:, c] for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')),
+                                            d['surface_wind_u'][c], d['surface_wind_v'][c], d['wind_u'][:, c], d['wind_v'][:, c],
+                                            d['wind_height_above_surface'][:, c])
+                for k in rm:
+                    a_, b_ = float(np.asarray(gm[k])[i]), float(rm[k])
+                    assert (np.isnan(a_) and np.isnan(b_)) or abs(a_ - b_) <= 1e-6 * max(1.0, abs(b_)), (k, c, a_, b_)
+    finally:
+        po.set_moist_lapse('ode')
     # the xarray-facing mirror: same numbers, reference names / attrs
     from xarray_parcel_amd import parcel_functions as pf
     from xarray_parcel_amd._xr import DataArray, Dataset
@@ -220,6 +236,7 @@ def test_conv_properties_and_storm_proxies_vs_oracle(xa):
     props = pf.conv_properties(ds)
     assert props['mixed_100_dci'].attrs['units'] == 'C' and props['mu_cape'].dims == ('point',)
     assert np.allclose(props['mu_cape'].values, np.asarray(got['mu_cape']), equal_nan=True)
+    assert set(pf.min_conv_properties(ds).keys()) >= {'mixed_100_cape', 'temp_500', 'shear_magnitude'}
     prox = pf.storm_proxies(props)
     assert prox['proxy_Kunz2007'].attrs['long_name'] == 'Proxy Kunz 2007'
     assert np.array_equal(prox['proxy_SHIP_0.1'].values.astype(bool), np.asarray(gp['proxy_SHIP_0.1']).astype(bool))

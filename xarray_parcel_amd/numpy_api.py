@@ -570,6 +570,26 @@ def conv_properties(dat, ignore_nans=False):
     return out
 
 
+def min_conv_properties(dat):
+    """pf.py:1873: the minimal bundle -- 100 hPa mixed-layer CAPE / CIN and lifted index, 700-500 hPa lapse rate, 500 hPa
+    temperature, freezing and melting level, 0-6 km shear.  Same input mapping as conv_properties(); no NaN blanking
+    (the reference has none here)."""
+    host_in = not any(_is_torch(v) for v in dat.values())
+    if host_in and torch is not None and torch.cuda.is_available():
+        dat = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).cuda() for k, v in dat.items()}
+    p, t, z = dat['pressure'], dat['temperature'], dat['height_asl']
+    td = dewpoint_from_specific_humidity(p, t, dat['specific_humidity'])
+    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, want_profile=True)
+    out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': lifted_index(ml['profile']),
+           'lapse_rate_700_500': lapse_rate(p, t, z), 'temp_500': isobar_temperature(p, t, 500.0),
+           'freezing_level': freezing_level_height(t, z), 'melting_level': melting_level_height(p, t, td, z)[0]}
+    out.update(wind_shear(dat['surface_wind_u'], dat['surface_wind_v'], dat['wind_u'], dat['wind_v'],
+                          dat['wind_height_above_surface']))
+    if host_in:
+        out = {k: (v.cpu().numpy() if _is_torch(v) else v) for k, v in out.items()}
+    return out
+
+
 def storm_proxies(dat):
     """pf.py:2323: hail / storm proxies (booleans) and SHIP from the output of conv_properties()."""
     nan = float('nan')

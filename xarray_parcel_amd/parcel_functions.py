@@ -470,12 +470,16 @@ _BUNDLE_ATTRS = {
 def conv_properties(dat, vert_dim=VERT, ignore_nans=False):
     """pf.py:1951: the convective-property bundle.  `dat` holds pressure, temperature, specific_humidity, height_asl on
     `vert_dim`, wind_u, wind_v, wind_height_above_surface on their own vertical, surface_wind_u, surface_wind_v."""
+    return _bundle(dat, vert_dim, _api.conv_properties, ignore_nans=ignore_nans)
+
+
+def _bundle(dat, vert_dim, fn, **kw):
     p, dims, coords, _ = _split(dat['pressure'], vert_dim)
     wdim = [d for d in dat['wind_u'].dims if d not in dims][0]
     arrs = {k: _split(dat[k], vert_dim)[0] for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')}
     arrs.update({k: _split(dat[k], wdim)[0] for k in ('wind_u', 'wind_v', 'wind_height_above_surface')})
     arrs.update({k: _split(dat[k], vert_dim)[0] for k in ('surface_wind_u', 'surface_wind_v')})
-    r = _api.conv_properties(arrs, ignore_nans=ignore_nans)
+    r = fn(arrs, **kw)
     out = Dataset()
     for k, v in r.items():
         attrs = dict(_BUNDLE_ATTRS.get(k, {}))
@@ -488,6 +492,12 @@ def conv_properties(dat, vert_dim=VERT, ignore_nans=False):
             attrs = {'long_name': 'Deep convective index', 'units': 'C'}
         out[k] = _horiz(_np(v), dims, coords, attrs=attrs, name=k)
     return out
+
+
+def min_conv_properties(dat, vert_dim=VERT):
+    """pf.py:1873: the minimal property set (mixed-layer CAPE/CIN + lifted index, lapse rate, T500, freezing / melting
+    level, 0-6 km shear)."""
+    return _bundle(dat, vert_dim, _api.min_conv_properties)
 
 
 def storm_proxies(dat):
