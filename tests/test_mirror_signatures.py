@@ -1,0 +1,56 @@
+"""The drop-in boundary is the reference's Python signatures: every function the mirror provides must take
+the reference's arguments, in its order, with its defaults.  Reference side: tests/golden/reference_signatures.json
+(extracted from modules/parcel_functions.py / parcel_test.py by tests/golden/make_signatures.py)."""
+import ast
+import inspect
+import json
+import os
+
+import pytest
+
+from xarray_parcel_amd import parcel_functions as pf
+from xarray_parcel_amd import parcel_test as pt
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_signatures.json')))
+# mirror-only extras that are allowed on top of the reference's arguments (always keyword, always after them)
+EXTRA = {'moist_lapse': {'moist'}, 'surface_cape_vector': {'fused'}, 'melting_level_height': set(), 'benchmark_cape': {'vert_dim'},
+         'dewpoint_from_specific_humidity': set()}
+# deliberately not mirrored: internals of the reference's array implementation that the streaming kernel replaces, its
+# table generator / notebook helpers, and the MetPy / serial comparison legs of the harness
+NOT_MIRRORED_OK = True
+
+
+def _mirrored(mod, ref):
+    return sorted(n for n in ref if hasattr(mod, n) and inspect.isfunction(getattr(mod, n)) and not n.startswith('_'))
+
+
+@pytest.mark.parametrize('modname,mod', [('parcel_functions', pf), ('parcel_test', pt)])
+def test_signatures_match_the_reference(modname, mod):
+    ref = GOLD[modname]
+    names = _mirrored(mod, ref)
+    assert len(names) >= (30 if modname == 'parcel_functions' else 3), names
+    for n in names:
+        sig = inspect.signature(getattr(mod, n))
+        params = [p for p in sig.parameters.values() if p.kind in (p.POSITIONAL_OR_KEYWORD, p.KEYWORD_ONLY)]
+        got = [p.name for p in params]
+        want = ref[n]['args']
+        assert got[:len(want)] == want, (n, got, want)
+        assert set(got[len(want):]) <= EXTRA.get(n, set()), (n, got[len(want):])
+        for p, d in zip(params, ref[n]['defaults']):
+            if d is None:
+                assert p.default is inspect.Parameter.empty, (n, p.name)
+            else:
+                assert p.default is not inspect.Parameter.empty and p.default == ast.literal_eval(d), (n, p.name, p.default, d)
+        if ref[n]['kwargs']:
+            assert any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values()), (n, 'missing **kwargs')
+
+
+def test_hot_path_functions_are_all_there():
+    need = ['surface_based_cape_cin', 'most_unstable_cape_cin', 'mixed_layer_cape_cin', 'cape_cin', 'parcel_profile',
+            'parcel_profile_with_lcl', 'lfc_el', 'cape_cin_base', 'lcl', 'moist_lapse', 'dry_lapse', 'most_unstable_parcel',
+            'mixed_parcel', 'mixed_layer', 'load_moist_adiabat_lookups', 'wet_bulb_temperature', 'lifted_index',
+            'deep_convective_index', 'lapse_rate', 'isobar_temperature', 'freezing_level_height', 'melting_level_height',
+            'wind_shear', 'significant_hail_parameter', 'conv_properties', 'min_conv_properties', 'storm_proxies']
+    missing = [n for n in need if not hasattr(pf, n)]
+    assert not missing, missing
+    assert all(n in GOLD['parcel_functions'] for n in need)
