@@ -228,6 +228,10 @@ int xp_dewpoint_from_specific_humidity(const xp_view *pressure, const xp_view *t
    constant `value`; NaN where the profile never crosses it.  One value per column. */
 int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *out, void *stream);
 
+/* pf.py:684-710 mixing_ratio: w = RH(T, Td) * w_s(p, T) [kg/kg], element-wise (MetPy 1.4.1 forms, pf.py:698-704); out has
+   the layout of `temperature`.  (virtual_temperature, pf.py:782-804, is T (1 + 0.608 w): plain arithmetic in the mirror.) */
+int xp_mixing_ratio(const xp_view *temperature, const xp_view *dewpoint, const xp_view *pressure, void *out, void *stream);
+
 const char *xp_last_error(void);
 
 #ifdef __cplusplus

@@ -60,6 +60,24 @@ def test_dewpoint_from_specific_humidity(xa):
     assert np.max(np.abs(g32[ok] - r32[ok])) <= 3e-5
 
 
+def test_mixing_ratio_and_virtual_temperature(xa):
+    """pf.py:684 / pf.py:782 element-wise, against the oracle's MetPy 1.4.1 forms (bit-for-bit up to libm: 1e-15 relative)."""
+    p, t, td = synth.columns(nlev=20, ncol=300, seed=61, nan_fraction=0.05, dtype=np.float64)
+    w = xa.mixing_ratio(t, td, p)
+    with np.errstate(all='ignore'):
+        ref = po.mixing_ratio(t, td, p)
+    assert w.shape == t.shape and np.array_equal(np.isnan(w), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(w[ok] / ref[ok] - 1.0)) <= 1e-14
+    tv = xa.virtual_temperature(t, w)
+    assert np.nanmax(np.abs(tv - po.virtual_temperature(t, ref))) <= 1e-10
+    from xarray_parcel_amd import parcel_functions as pf
+    from xarray_parcel_amd._xr import DataArray
+    W = pf.mixing_ratio(DataArray(t, dims=('z', 'c')), DataArray(td, dims=('z', 'c')), DataArray(p, dims=('z', 'c')))
+    assert W.attrs['units'] == 'kg kg$^{-1}$' and np.allclose(W.values, w, equal_nan=True)
+    assert pf.virtual_temperature(DataArray(t, dims=('z', 'c')), W).attrs['long_name'] == 'Virtual temperature'
+
+
 @pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_fused_specific_humidity_input(xa, parcel, dtype):

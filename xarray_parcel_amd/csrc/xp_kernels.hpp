@@ -626,6 +626,18 @@ void k_crossing_level(View xv, View av, int64_t nlev, int64_t ncol, double value
     st(out, sizeof(T) == 8, c, best);
 }
 
+// mixing_ratio (pf.py:684-710): RH = e_s(Td) / e_s(T) times the saturation mixing ratio at (p, T) -- MetPy 1.4.1's
+// relative_humidity_from_dewpoint + mixing_ratio_from_relative_humidity, in the reference's operation order
+template <typename T> __global__ __launch_bounds__(256)
+void k_mixing_ratio(View tv, View tdv, View pv, int64_t nlev, int64_t ncol, OutView out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nlev * ncol) return;
+    int64_t k = e / ncol, c = e - k * ncol;
+    double t = ld<T>(tv, k, c), td = ld<T>(tdv, k, c), p = ld<T>(pv, k, c);
+    double est = es_ref(t);
+    st(out.data, sizeof(T) == 8, k * out.ls + c * out.cs, (es_ref(td) / est) * (EPS * est / (p - est)));
+}
+
 // dense (nlev, ncol) copy of a strided view: the fall-back for inputs whose three views do not share strides (or
 // whose column offsets exceed 32 bits), see CapeArgs::off32
 template <typename T> __global__ __launch_bounds__(256)

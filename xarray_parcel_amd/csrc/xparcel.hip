@@ -638,4 +638,24 @@ int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *ou
     return st.finish();
 }
 
+int xp_mixing_ratio(const xp_view *t, const xp_view *td, const xp_view *p, void *out, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(t, "temperature")) || (rc = check_view(td, "dewpoint")) || (rc = check_view(p, "pressure")) ||
+        (rc = same_shape(t, td, "temperature/dewpoint")) || (rc = same_shape(t, p, "temperature/pressure"))) return rc;
+    if (!out) return fail(XP_E_ARG, "xp_mixing_ratio: null output");
+    Stager st(stream);
+    xp::View tv, tdv, pv; xp::OutView ov;
+    void *od;
+    if ((rc = stage_view(st, t, &tv)) || (rc = stage_view(st, td, &tdv)) || (rc = stage_view(st, p, &pv)) ||
+        (rc = st.out(out, (size_t)t->nlev * (size_t)t->ncol * esize(t->dtype), t->mem, &od))) return rc;
+    ov.data = od; ov.ls = t->lev_stride; ov.cs = t->col_stride;
+    int64_t n = t->nlev * t->ncol;
+    if (n) {
+        if (t->dtype == XP_F64) hipLaunchKernelGGL((xp::k_mixing_ratio<double>), dim3(blocks(n)), dim3(256), 0, st.s, tv, tdv, pv, t->nlev, t->ncol, ov);
+        else hipLaunchKernelGGL((xp::k_mixing_ratio<float>), dim3(blocks(n)), dim3(256), 0, st.s, tv, tdv, pv, t->nlev, t->ncol, ov);
+    }
+    return st.finish();
+}
+
 }  // extern "C"

@@ -423,6 +423,24 @@ def dewpoint_from_specific_humidity(pressure, temperature, specific_humidity):
     return out.reshape((nlev,) + hshape)
 
 
+def mixing_ratio(temperature, dewpoint, pressure):
+    """pf.py:684: RH(T, Td) x saturation mixing ratio at (p, T) [kg/kg]."""
+    (t, td, p), dt, dev = _common(temperature, dewpoint, pressure)
+    assert t.shape == td.shape == p.shape, 'temperature, dewpoint, pressure must share a shape'
+    shape = t.shape
+    n = int(np.prod(shape)) if shape else 1
+    lib = L.init(_device_of(t))
+    out, optr = _alloc((n,), dt, dev, t)
+    L.check(lib.xp_mixing_ratio(C.byref(_view(t, 1, n)), C.byref(_view(td, 1, n)), C.byref(_view(p, 1, n)),
+                                C.c_void_p(optr), _stream(dev)))
+    return out.reshape(shape)
+
+
+def virtual_temperature(temperature, mixing_ratio, epsilon=0.608):
+    """pf.py:782 (Doswell & Rasmussen 1994): one multiply-add, plain array arithmetic."""
+    return temperature * (1 + epsilon * mixing_ratio)
+
+
 def crossing_level(x, a, value):
     """Smallest x over all intersections of the profile a(x) with the constant `value` (find_intersections
     pf.py:992 + the min of pf.py:2153): freezing_level_height is crossing_level(height, temperature, 273.15)."""

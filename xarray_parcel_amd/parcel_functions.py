@@ -344,6 +344,24 @@ def lifted_index(profile, vert_dim=VERT, description=None, prefix=None):
     return Dataset({name: _horiz(_np(_api.lifted_index(prof)), dims, coords, attrs=attrs, name=name)})
 
 
+def mixing_ratio(temperature, dewpoint, pressure):
+    """pf.py:684."""
+    if not isinstance(temperature, DataArray):
+        return _np(_api.mixing_ratio(temperature, dewpoint, pressure))
+    out = _np(_api.mixing_ratio(np.asarray(temperature.values), np.asarray(getattr(dewpoint, 'values', dewpoint)),
+                                np.asarray(getattr(pressure, 'values', pressure))))
+    return DataArray(out, dims=temperature.dims, coords=temperature.coords, attrs={'units': 'kg kg$^{-1}$'})
+
+
+def virtual_temperature(temperature, mixing_ratio, epsilon=0.608):
+    """pf.py:782."""
+    res = temperature * (1 + epsilon * mixing_ratio)
+    if isinstance(res, DataArray):
+        res.attrs['units'] = 'K'
+        res.attrs['long_name'] = 'Virtual temperature'
+    return res
+
+
 def wet_bulb_temperature_fast(temperature, dewpoint):
     """pf.py:364: "1/3 rule" estimate (array arithmetic on the DataArrays, as in the reference)."""
     wb = temperature - (1 / 3) * (temperature - dewpoint)
