@@ -167,8 +167,10 @@ static void moist_lapse_table(int n, const double *p, double t0, double pref, do
     double i0 = floor(fi), j0 = floor(fj);
     int64_t ip = (int64_t)(((i0 + 1.0) - fi < fi - i0) ? i0 + 1.0 : i0);
     int64_t jt = (int64_t)(((j0 + 1.0) - fj <= fj - j0) ? j0 + 1.0 : j0);
-    if (ip < 0) ip = 0; if (ip > T->n_p - 1) ip = T->n_p - 1;
-    if (jt < 0) jt = 0; if (jt > T->n_t - 1) jt = T->n_t - 1;
+    if (ip < 0) ip = 0;
+    if (ip > T->n_p - 1) ip = T->n_p - 1;
+    if (jt < 0) jt = 0;
+    if (jt > T->n_t - 1) jt = T->n_t - 1;
     uint16_t a = T->index[ip * T->n_t + jt];
     if (a == 0) return;                                          /* NaN cell: pf.py:570-582 */
     const float *row = T->adiabats + (int64_t)(a - 1) * T->n_p; /* ascending p: row[k] at p_min + k*step */
@@ -588,7 +590,7 @@ int xpo_most_unstable_parcel(int n, const double *p, const double *t, const doub
    (get_layer pf.py:63-100 interpolate=True, mixed_layer pf.py:137-162) */
 static double mixed_layer_mean(int n, const double *p, const double *v, double depth) {
     size_t N = (size_t)n;
-    double *buf = (double *)malloc(sizeof(double) * (3 * N + 2 * (N + 1)));
+    double *buf = (double *)calloc(3 * N + 2 * (N + 1), sizeof(double));
     double *lp = buf, *pi = buf + N, *vi = pi + N + 1, *dummy = vi + N + 1;
     (void)dummy;
     double bottom = nmax(p, n), top = bottom - depth;
