@@ -28,3 +28,19 @@ def test_bench_json_contract():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert d['value'] > 1e6
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """The N > 1 control flow of bench.py (slab per rank, side-stream gather, barrier + max-over-ranks timing) with two
+    ranks sharing cuda:0 and a gloo gather -- the RCCL path proper needs the driver's multi-GPU node."""
+    env = dict(os.environ, XPARCEL_BENCH_SINGLE_DEVICE='1', XPARCEL_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--ny', '64',
+           '--no-cpu']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and 'cpu_baseline' not in d
+    assert d['config']['columns_per_gpu'] == 64 * 1024
