@@ -24,8 +24,15 @@
  *   - every function returns 0 on success or a negative XP_E* code; the message is
  *     available from xp_last_error() (thread-local).  The reference's data-dependent
  *     asserts (pf.py:131, 1149, 1158) become per-column status bits, not aborts;
- *   - re-entrant; work is enqueued on the hipStream_t passed as `stream` (NULL = the
- *     default stream).  Device-resident calls return without synchronising; calls with
+ *   - one device per process (the deployment model is one process per GPU): xp_init(device)
+ *     binds the library's state -- lookup tables, the e_s / ln / adiabat-family tables -- to that
+ *     device, and every call runs there whatever the calling thread's current device is (which
+ *     is restored on return).  Calls from several host threads are safe against each other;
+ *     replacing tables (xp_set_tables, xp_set_family_table, xp_init on another device) waits for
+ *     the device to drain first and must not race with other calls;
+ *   - work is enqueued on the hipStream_t passed as `stream` (NULL = the default stream), which
+ *     must belong to the library's device.  Device-resident calls return without synchronising
+ *     (an asynchronous kernel fault surfaces at the caller's next synchronisation); calls with
  *     host buffers synchronise the stream before returning.
  */
 #ifndef XPARCEL_H

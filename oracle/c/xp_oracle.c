@@ -189,108 +189,182 @@ static void moist_lapse_table(int n, const double *p, double t0, double pref, do
 }
 
 /* ---- "adiabat family" exact mode (specification: oracle/family.py) ------------------------------------------- */
-#define FAM_XLO 3.4011973816621555 /* ln 30 */
-#define FAM_DX 0.028
-#define FAM_NX 133
-#define FAM_SLO 215.0
-#define FAM_DS 0.5
-#define FAM_NS 201
+/* T(x ; psi) = sum_n sum_m A[j][n][m][q] z^n s^m on x-pieces j (width 0.5 in ln p below ln 1100) and psi-pieces q
+ * (EDGES); A = monomial form of the 9 x 9 Chebyshev-node interpolant of the ODE solution; layout [j][n][m][q]. */
+#define FAM_XHI 7.003065458786462 /* ln 1100 */
+#define FAM_WX 0.5
+#define FAM_NPX 8
+#define FAM_XLO (FAM_XHI - FAM_WX * FAM_NPX)
+#define FAM_ND 8
+#define FAM_MD 8
+#define FAM_NPS 9
 #define FAM_X1000 6.907755278982137
-#define FAM_SUB 8
+#define FAM_BUILD_H 0.0125
+#define FAM_LABEL_H 0.25
+#define FAM_MARGIN 0.05
+#define FAM_NEWTON 3
+#define FAM_SIZE (FAM_NPX * (FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS)
+static const double FAM_EDGES[FAM_NPS + 1] = {215.0, 245.0, 262.0, 275.0, 285.0, 293.0, 299.0, 304.0, 308.5, 312.0};
 static double *g_fam = NULL;
 
+static double fam_rk4(double x, double t, double x1, double h_max) {
+    int n = (int)ceil(fabs(x1 - x) / h_max - 1e-12);
+    if (n < 1) n = 1;
+    double h = (x1 - x) / n;
+    for (int s = 0; s < n; s++) {
+        double k1 = dt_dlnp(x, t);
+        double k2 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
+        double k3 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
+        double k4 = dt_dlnp(x + h, t + h * k3);
+        t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+        x = x + h;
+    }
+    return t;
+}
+static double fam_xmid(int j) { return FAM_XHI - FAM_WX * (j + 0.5); }
+static double fam_smid(int q) { return 0.5 * (FAM_EDGES[q] + FAM_EDGES[q + 1]); }
+static double fam_shalf(int q) { return 0.5 * (FAM_EDGES[q + 1] - FAM_EDGES[q]); }
+/* solve V c = y for the monomial coefficients of the interpolant through (u_k, y_k), k < n (n <= 9) */
+static void fam_monomials(int n, const double *u, const double *y, double *c) {
+    long double A[9][10];
+    for (int k = 0; k < n; k++) {
+        long double v = 1.0L;
+        for (int i = 0; i < n; i++) { A[k][i] = v; v *= (long double)u[k]; }
+        A[k][n] = (long double)y[k];
+    }
+    for (int col = 0; col < n; col++) {
+        int piv = col;
+        for (int r = col + 1; r < n; r++) if (fabsl(A[r][col]) > fabsl(A[piv][col])) piv = r;
+        for (int i = 0; i <= n; i++) { long double t_ = A[col][i]; A[col][i] = A[piv][i]; A[piv][i] = t_; }
+        for (int r = 0; r < n; r++) {
+            if (r == col) continue;
+            long double f = A[r][col] / A[col][col];
+            for (int i = col; i <= n; i++) A[r][i] -= f * A[col][i];
+        }
+    }
+    for (int i = 0; i < n; i++) c[i] = (double)(A[i][n] / A[i][i]);
+}
 static void fam_build(double *tab) {
-    int i_up = (int)floor((FAM_X1000 - FAM_XLO) / FAM_DX);
-    for (int j = 0; j < FAM_NS; j++) {
-        for (int dir = -1; dir <= 1; dir += 2) {
-            double t = FAM_SLO + FAM_DS * j, x = FAM_X1000;
-            for (int i = (dir < 0 ? i_up : i_up + 1); i >= 0 && i < FAM_NX; i += dir) {
-                double x1 = FAM_XLO + FAM_DX * i, h = (x1 - x) / FAM_SUB;
-                for (int s = 0; s < FAM_SUB; s++) {
-                    double k1 = dt_dlnp(x, t);
-                    double k2 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
-                    double k3 = dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
-                    double k4 = dt_dlnp(x + h, t + h * k3);
-                    t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
-                    x = x + h;
-                }
-                x = x1;
-                tab[(size_t)i * FAM_NS + j] = t;
+    enum { NN = FAM_ND + 1, MM = FAM_MD + 1, NXN = FAM_NPX * (FAM_ND + 1), NSN = FAM_NPS * (FAM_MD + 1) };
+    const double pi = 3.14159265358979323846;
+    double un[NN], um[MM], xs[NXN], ps[NSN];
+    double *vals = (double *)malloc(sizeof(double) * NXN * NSN);
+    for (int k = 0; k < NN; k++) un[k] = cos(pi * (k + 0.5) / NN);
+    for (int k = 0; k < MM; k++) um[k] = cos(pi * (k + 0.5) / MM);
+    for (int j = 0; j < FAM_NPX; j++) for (int k = 0; k < NN; k++) xs[j * NN + k] = fam_xmid(j) + 0.5 * FAM_WX * un[k];
+    for (int q = 0; q < FAM_NPS; q++) for (int k = 0; k < MM; k++) ps[q * MM + k] = fam_smid(q) + fam_shalf(q) * um[k];
+    /* x-nodes in order of distance from ln 1000, each side separately */
+    for (int side = 0; side < 2; side++) {
+        int order[NXN], cnt = 0;
+        for (int i = 0; i < NXN; i++) if ((side == 0) == (xs[i] <= FAM_X1000)) order[cnt++] = i;
+        for (int a = 1; a < cnt; a++) {                    /* insertion sort by |x - ln 1000| (stable) */
+            int v = order[a], b = a - 1;
+            while (b >= 0 && fabs(xs[order[b]] - FAM_X1000) > fabs(xs[v] - FAM_X1000)) { order[b + 1] = order[b]; b--; }
+            order[b + 1] = v;
+        }
+        for (int c = 0; c < NSN; c++) {
+            double x = FAM_X1000, t = ps[c];
+            for (int a = 0; a < cnt; a++) {
+                int i = order[a];
+                if (xs[i] != x) { t = fam_rk4(x, t, xs[i], FAM_BUILD_H); x = xs[i]; }
+                vals[(size_t)i * NSN + c] = t;
             }
         }
     }
+    for (int j = 0; j < FAM_NPX; j++)
+        for (int q = 0; q < FAM_NPS; q++) {
+            double a[NN][MM], col[NN], cf[NN], row[MM], rf[MM];
+            for (int m = 0; m < MM; m++) {                 /* monomials in z for every psi-node ... */
+                for (int k = 0; k < NN; k++) col[k] = vals[(size_t)(j * NN + k) * NSN + (q * MM + m)];
+                fam_monomials(NN, un, col, cf);
+                for (int n = 0; n < NN; n++) a[n][m] = cf[n];
+            }
+            for (int n = 0; n < NN; n++) {                 /* ... then in s for every z-coefficient */
+                for (int m = 0; m < MM; m++) row[m] = a[n][m];
+                fam_monomials(MM, um, row, rf);
+                for (int m = 0; m < MM; m++) tab[(((size_t)j * NN + n) * MM + m) * FAM_NPS + q] = rf[m];
+            }
+        }
+    free(vals);
 }
 const double *xpo_family_table(void) {
-    if (!g_fam) { g_fam = (double *)malloc(sizeof(double) * FAM_NX * FAM_NS); fam_build(g_fam); }
+    if (!g_fam) { g_fam = (double *)malloc(sizeof(double) * FAM_SIZE); fam_build(g_fam); }
     return g_fam;
 }
-static void lagrange6(double t, double *w) {
-    double a = t + 2.0, b = t + 1.0, c = t, d = t - 1.0, e = t - 2.0, g = t - 3.0;
-    w[0] = -(b * c * d * e * g) / 120.0; w[1] = (a * c * d * e * g) / 24.0; w[2] = -(a * b * d * e * g) / 12.0;
-    w[3] = (a * b * c * e * g) / 12.0; w[4] = -(a * b * c * d * g) / 24.0; w[5] = (a * b * c * d * e) / 120.0;
+/* tests hand one table to both sides: replace the oracle's own */
+void xpo_set_family_table(const double *tab) {
+    xpo_family_table();
+    memcpy(g_fam, tab, sizeof(double) * FAM_SIZE);
 }
-static void dlagrange6(double t, double *w) {
-    const double n[6] = {-2, -1, 0, 1, 2, 3}, den[6] = {-120, 24, -12, 12, -24, 120};
-    for (int k = 0; k < 6; k++) {
-        double s = 0;
-        for (int skip = 0; skip < 6; skip++) {
-            if (skip == k) continue;
-            double prod = 1;
-            for (int m = 0; m < 6; m++) if (m != k && m != skip) prod *= (t - n[m]);
-            s += prod;
-        }
-        w[k] = s / den[k];
+static double fam_a(const double *tab, int j, int n, int m, int q) {
+    return tab[(((size_t)j * (FAM_ND + 1) + n) * (FAM_MD + 1) + m) * FAM_NPS + q];
+}
+static int fam_xpiece(double x) {
+    double j = floor((FAM_XHI - x) * (1.0 / FAM_WX));
+    return j < 0 ? 0 : (j > FAM_NPX - 1 ? FAM_NPX - 1 : (int)j);
+}
+static int fam_spiece(double psi) {
+    int q = 0;
+    while (q < FAM_NPS - 1 && psi >= FAM_EDGES[q + 1]) q++;
+    return q;
+}
+/* c_n = sum_m A[j][n][m][q] s^m */
+static void fam_column_poly(const double *tab, int j, int q, double s, double *c) {
+    for (int n = 0; n <= FAM_ND; n++) {
+        double v = fam_a(tab, j, n, FAM_MD, q);
+        for (int m = FAM_MD - 1; m >= 0; m--) v = v * s + fam_a(tab, j, n, m, q);
+        c[n] = v;
     }
 }
-static int fam_x_ok(double x) { double i = floor((x - FAM_XLO) / FAM_DX); return i - 2 >= 0 && i + 3 <= FAM_NX - 1; }
-static int fam_s_ok(double s) { double j = floor((s - FAM_SLO) / FAM_DS); return j - 2 >= 0 && j + 3 <= FAM_NS - 1; }
-static double fam_eval(const double *tab, double x, double psi) {
-    if (!(isfinite(x) && isfinite(psi)) || !fam_x_ok(x) || !fam_s_ok(psi)) return NAN;
-    double ux = (x - FAM_XLO) / FAM_DX, us = (psi - FAM_SLO) / FAM_DS;
-    int i = (int)floor(ux), j = (int)floor(us);
-    double wx[6], ws[6], r = 0;
-    lagrange6(ux - i, wx); lagrange6(us - j, ws);
-    for (int b = 0; b < 6; b++) {
-        double row = 0;
-        for (int a = 0; a < 6; a++) row += tab[(size_t)(i - 2 + b) * FAM_NS + (j - 2 + a)] * ws[a];
-        r += wx[b] * row;
-    }
-    return r;
+static double fam_horner(int deg, const double *c, double u) {
+    double v = c[deg];
+    for (int k = deg - 1; k >= 0; k--) v = v * u + c[k];
+    return v;
 }
-static double fam_label(const double *tab, double x_lcl, double t_lcl) {
-    if (!(isfinite(x_lcl) && isfinite(t_lcl)) || !fam_x_ok(x_lcl)) return NAN;
-    double lo = FAM_SLO + 2.0 * FAM_DS, hi = FAM_SLO + FAM_DS * (FAM_NS - 3) - 1e-9;
-    double psi = t_lcl + dt_dlnp(x_lcl, t_lcl) * (FAM_X1000 - x_lcl);
-    psi = psi < lo ? lo : (psi > hi ? hi : psi);
-    double ux = (x_lcl - FAM_XLO) / FAM_DX;
-    int i = (int)floor(ux);
-    double wx[6]; lagrange6(ux - i, wx);
-    for (int it = 0; it < 12; it++) {
-        double us = (psi - FAM_SLO) / FAM_DS; int j = (int)floor(us);
-        double ws[6], dws[6], fv = 0, dv = 0;
-        lagrange6(us - j, ws); dlagrange6(us - j, dws);
-        for (int a = 0; a < 6; a++) {
-            double col = 0;
-            for (int b = 0; b < 6; b++) col += wx[b] * tab[(size_t)(i - 2 + b) * FAM_NS + (j - 2 + a)];
-            fv += col * ws[a]; dv += col * dws[a];
-        }
-        fv -= t_lcl; dv /= FAM_DS;
-        double nw = psi - fv / dv;
-        nw = nw < lo ? lo : (nw > hi ? hi : nw);
-        int done = fabs(nw - psi) < 1e-10;
-        psi = nw;
-        if (done) break;
+/* label psi (and its piece q) of the adiabat through (x_lcl, t_lcl); NaN when outside the table */
+static double fam_label(const double *tab, double x_lcl, double t_lcl, int *q_out) {
+    *q_out = -1;
+    if (!(isfinite(x_lcl) && isfinite(t_lcl)) || !(x_lcl >= FAM_XLO && x_lcl <= FAM_XHI)) return NAN;
+    double psi0 = (x_lcl != FAM_X1000) ? fam_rk4(x_lcl, t_lcl, FAM_X1000, FAM_LABEL_H) : t_lcl;
+    if (!(psi0 >= FAM_EDGES[0] + FAM_MARGIN && psi0 <= FAM_EDGES[FAM_NPS] - FAM_MARGIN)) return NAN;
+    int q = fam_spiece(psi0), j = fam_xpiece(x_lcl);
+    double z = (x_lcl - fam_xmid(j)) * (2.0 / FAM_WX);
+    double b[FAM_MD + 1], db[FAM_MD];
+    for (int m = 0; m <= FAM_MD; m++) {
+        double v = fam_a(tab, j, FAM_ND, m, q);
+        for (int n = FAM_ND - 1; n >= 0; n--) v = v * z + fam_a(tab, j, n, m, q);
+        b[m] = v;
     }
-    if (!(fabs(fam_eval(tab, x_lcl, psi) - t_lcl) <= 1e-8)) return NAN;
+    for (int m = 1; m <= FAM_MD; m++) db[m - 1] = b[m] * m;
+    double inv_h = 1.0 / fam_shalf(q), psi = psi0;
+    for (int it = 0; it < FAM_NEWTON; it++) {
+        double s = (psi - fam_smid(q)) * inv_h;
+        psi = psi - (fam_horner(FAM_MD, b, s) - t_lcl) / (fam_horner(FAM_MD - 1, db, s) * inv_h);
+    }
+    if (!(fabs(psi - psi0) <= FAM_MARGIN)) return NAN;
+    *q_out = q;
     return psi;
+}
+static double fam_eval(const double *tab, double x, double psi, int q) {
+    if (!isfinite(x) || x > FAM_XHI) return NAN;
+    double s = (psi - fam_smid(q)) * (1.0 / fam_shalf(q));
+    double c[FAM_ND + 1];
+    if (x < FAM_XLO) {                                     /* above the table top: dry continuation */
+        fam_column_poly(tab, FAM_NPX - 1, q, s, c);
+        return fam_horner(FAM_ND, c, -1.0) * exp(KAPPA * (x - FAM_XLO));
+    }
+    int j = fam_xpiece(x);
+    fam_column_poly(tab, j, q, s, c);
+    return fam_horner(FAM_ND, c, (x - fam_xmid(j)) * (2.0 / FAM_WX));
 }
 static void moist_lapse_family(int n, const double *p, double t0, double pref, double *out) {
     const double *tab = xpo_family_table();
-    double psi = (pref > 0) ? fam_label(tab, log(pref), t0) : NAN;
+    int q = -1;
+    double psi = (pref > 0) ? fam_label(tab, log(pref), t0, &q) : NAN;
     int ok = !isnan(psi);
     for (int k = 0; k < n && ok; k++) {
         if (isnan(p[k])) { out[k] = NAN; continue; }
-        out[k] = (p[k] == pref) ? t0 : fam_eval(tab, log(p[k]), psi);
+        out[k] = (p[k] == pref) ? t0 : fam_eval(tab, log(p[k]), psi, q);
         if (isnan(out[k])) ok = 0;
     }
     if (!ok) moist_lapse_rk4(n, p, t0, pref, out);      /* label or a level outside the table: whole parcel by RK4 */

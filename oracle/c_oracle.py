@@ -113,11 +113,11 @@ def cape_cin_grid(p, t, td, parcel_values=None, want_profile=False, nthreads=0, 
 
 
 def family_table():
-    """The C oracle's adiabat-family table as a (NX, NS) float64 array (see oracle/family.py)."""
+    """The C oracle's adiabat-family table as a (NPX, NDEG+1, MDEG+1, NPS) float64 array (see oracle/family.py)."""
     from . import family as fam
     lib().xpo_family_table.restype = DP
     ptr = lib().xpo_family_table()
-    return np.ctypeslib.as_array(ptr, shape=(fam.NX, fam.NS)).copy()
+    return np.ctypeslib.as_array(ptr, shape=(fam.NPX, fam.NDEG + 1, fam.MDEG + 1, fam.NPS)).copy()
 
 
 def max_threads():

@@ -2,59 +2,99 @@
 oracle/family.py -- TEST INFRASTRUCTURE ONLY (CPU oracle).
 
 Specification of the build's second exact moist mode, the "adiabat family": instead of integrating MetPy's
-pseudo-adiabat ODE level by level (oracle/thermo.py moist_lapse_rk4), the family of its solutions is tabulated
-once,
+pseudo-adiabat ODE level by level (oracle/thermo.py moist_lapse_rk4), the one-parameter family of its solutions
+T(x ; psi), x = ln p, psi = the adiabat's temperature at 1000 hPa, is stored once as a piecewise polynomial:
 
-    TAB[i][j] = T(X_i ; psi_j),   X_i = ln(30 hPa) + i*DX (i < NX),   psi_j = 215 K + j*0.5 K (j < NS),
+    x-pieces   j = 0..NPX-1 : [XHI - WX*(j+1), XHI - WX*j],  XHI = ln 1100, WX = 0.5  (1100 hPa ... ~20.1 hPa)
+    psi-pieces q = 0..NPS-1 : [EDGES[q], EDGES[q+1]]  (215 ... 312 K, narrower towards the warm end)
+    T(x ; psi) = sum_n sum_m A[j][n][m][q] z^n s^m,   z, s = the piece-local coordinates in [-1, 1],  n, m <= 8
 
-where psi labels an adiabat by its temperature at 1000 hPa, and evaluated by 6 x 6 Lagrange interpolation
-(6 nodes in ln p around the level, 6 in psi around the column's label).  A column's label is the root of
-T(ln p_lcl ; psi) = T_lcl (Newton on the interpolant), so the interpolated adiabat passes through the LCL exactly.
-This plays the role of the reference's own lookup tables (pf.py:447-607) but is accurate to 1.4e-6 K against the
-ODE instead of 0.037 K (tests/test_oracle_family.py); points outside the table fall back to the RK4 mode.
+A[j][.][.][q] is the interpolant of the ODE solution at the 9 x 9 Chebyshev nodes of the piece (RK4 from ln 1000 with
+steps <= 1/80 in ln p, error ~1e-10 K), converted to monomials.  A column's label psi is found by one coarse RK4 march
+from its LCL to 1000 hPa (steps <= 0.25) followed by three Newton steps on the table inside the psi-piece the coarse
+label falls in, so that the tabulated adiabat passes through (p_lcl, T_lcl).  Above the table's top (~20 hPa) the adiabat
+continues dry (T ~ p^kappa; e_s / p < 1e-6 there).  This plays the role of the reference's own lookup tables
+(pf.py:447-607) but is accurate to < 1e-6 K against the ODE instead of 0.037 K (tests/test_oracle_family.py) -- closer
+to the ODE than the RK4 stepper (2e-5 K) or MetPy's LSODA tolerance; parcels whose label or LCL lie outside the table
+fall back to the RK4 mode.
 
-The table is built by classical RK4 in ln p with step DX/8 from 1000 hPa outwards (error ~1e-11 K), the same
-recipe the product's xp_init uses -- written independently on both sides; the parity tests hand the oracle's
-table to the device so that both interpolate identical numbers.
+The product builds the same table in xp_init by the same recipe, written independently; the parity tests hand the
+oracle's table to the device so that both evaluate identical numbers.
 """
 import numpy as np
 
 from . import thermo as th
 
-XLO = float(np.log(30.0))
-DX = 0.028
-NX = 133                      # up to ln(30) + 132*0.028 = ln(1208 hPa)
-SLO, DS, NS = 215.0, 0.5, 201  # 215 ... 315 K
+XHI = float(np.log(1100.0))
+WX = 0.5
+NPX = 8
+XLO = XHI - WX * NPX            # ~ ln 20.15 hPa: table top
+NDEG = 8                        # degree in x (9 coefficients per piece)
+MDEG = 8                        # degree in psi
+EDGES = np.array([215.0, 245.0, 262.0, 275.0, 285.0, 293.0, 299.0, 304.0, 308.5, 312.0])
+NPS = len(EDGES) - 1
 X1000 = float(np.log(1000.0))
-SUB = 8                        # RK4 substeps per table interval
+BUILD_H = 0.0125                # RK4 step bound of the table build
+LABEL_H = 0.25                  # RK4 step bound of the coarse label
+LABEL_MARGIN = 0.05             # coarse label must be this far inside [EDGES[0], EDGES[-1]]; Newton may move it this far
+NEWTON_STEPS = 3
 
 
 def _f(x, t):
     return th._moist_dt_dlnp(x, t)
 
 
+def _rk4(x, t, x1, h_max):
+    """March from x to x1 in ceil(|x1 - x| / h_max) equal RK4 steps (t may be a vector)."""
+    n = max(1, int(np.ceil(abs(x1 - x) / h_max - 1e-12)))
+    h = (x1 - x) / n
+    for _ in range(n):
+        k1 = _f(x, t)
+        k2 = _f(x + 0.5 * h, t + 0.5 * h * k1)
+        k3 = _f(x + 0.5 * h, t + 0.5 * h * k2)
+        k4 = _f(x + h, t + h * k3)
+        t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        x = x + h
+    return t
+
+
+def x_mid(j):
+    return XHI - WX * (j + 0.5)
+
+
+def psi_mid(q):
+    return 0.5 * (EDGES[q] + EDGES[q + 1])
+
+
+def psi_half(q):
+    return 0.5 * (EDGES[q + 1] - EDGES[q])
+
+
 def build_table():
-    """(NX, NS) float64: vectorised over psi, RK4 with step DX/SUB marching away from ln 1000 on both sides.
-    X_i are not aligned with ln 1000, so the first leg on each side is a partial step."""
-    psi = SLO + DS * np.arange(NS)
-    tab = np.empty((NX, NS))
-    i_up = int(np.floor((X1000 - XLO) / DX))          # last node with X_i <= ln 1000
-    for direction in (-1, +1):
-        t = psi.copy()
-        x = X1000
-        rng = range(i_up, -1, -1) if direction < 0 else range(i_up + 1, NX)
-        for i in rng:
-            x1 = XLO + DX * i
-            h = (x1 - x) / SUB
-            for _ in range(SUB):
-                k1 = _f(x, t)
-                k2 = _f(x + 0.5 * h, t + 0.5 * h * k1)
-                k3 = _f(x + 0.5 * h, t + 0.5 * h * k2)
-                k4 = _f(x + h, t + h * k3)
-                t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
-                x = x + h
-            x = x1
-            tab[i] = t
+    """(NPX, NDEG+1, MDEG+1, NPS) float64.  Nodes: Chebyshev points of the first kind of every piece; every psi-node's
+    adiabat is marched away from ln 1000 on both sides through the x-nodes in order of distance."""
+    un = np.cos(np.pi * (np.arange(NDEG + 1) + 0.5) / (NDEG + 1))
+    um = np.cos(np.pi * (np.arange(MDEG + 1) + 0.5) / (MDEG + 1))
+    xs = np.concatenate([x_mid(j) + 0.5 * WX * un for j in range(NPX)])
+    ps = np.concatenate([psi_mid(q) + psi_half(q) * um for q in range(NPS)])
+    vals = np.empty((xs.size, ps.size))
+    for side in (xs <= X1000, xs > X1000):
+        idx = np.nonzero(side)[0]
+        idx = idx[np.argsort(np.abs(xs[idx] - X1000), kind='stable')]
+        x, t = X1000, ps.copy()
+        for i in idx:
+            if xs[i] != x:
+                t = _rk4(x, t, xs[i], BUILD_H)
+                x = xs[i]
+            vals[i] = t
+    vn = np.vander(un, NDEG + 1, increasing=True)
+    vm = np.vander(um, MDEG + 1, increasing=True)
+    tab = np.empty((NPX, NDEG + 1, MDEG + 1, NPS))
+    for j in range(NPX):
+        for q in range(NPS):
+            blk = vals[j * (NDEG + 1):(j + 1) * (NDEG + 1), q * (MDEG + 1):(q + 1) * (MDEG + 1)]
+            a = np.linalg.solve(vn, blk)                # monomials in z (rows) ...
+            tab[j, :, :, q] = np.linalg.solve(vm, a.T).T   # ... and in s (columns)
     return tab
 
 
@@ -67,77 +107,60 @@ def table():
     return _cache['tab']
 
 
-def lagrange6(t):
-    """Weights of the 6-point Lagrange interpolant on nodes -2..3 at fractional position t in [0, 1)."""
-    a, b, c, d, e, g = t + 2.0, t + 1.0, t, t - 1.0, t - 2.0, t - 3.0
-    return np.array([-(b * c * d * e * g) / 120.0, (a * c * d * e * g) / 24.0, -(a * b * d * e * g) / 12.0,
-                     (a * b * c * e * g) / 12.0, -(a * b * c * d * g) / 24.0, (a * b * c * d * e) / 120.0])
+def x_piece(x):
+    """Piece of ln p = x: floor((XHI - x) / WX) clipped to the table; x must lie in [XLO, XHI]."""
+    return int(min(max(np.floor((XHI - x) * (1.0 / WX)), 0), NPX - 1))
 
 
-def dlagrange6(t):
-    """d/dt of lagrange6 (product rule on the five-factor numerators)."""
-    n = np.array([-2.0, -1.0, 0.0, 1.0, 2.0, 3.0])
-    den = np.array([-120.0, 24.0, -12.0, 12.0, -24.0, 120.0])
-    out = np.zeros(6)
-    for k in range(6):
-        others = [m for m in range(6) if m != k]
-        s = 0.0
-        for skip in others:
-            prod = 1.0
-            for m in others:
-                if m != skip:
-                    prod *= (t - n[m])
-            s += prod
-        out[k] = s / den[k]
-    return out
+def psi_piece(psi):
+    return int(min(max(np.searchsorted(EDGES, psi, side='right') - 1, 0), NPS - 1))
 
 
-def in_x_range(x):
-    i = np.floor((x - XLO) / DX)
-    return (i - 2 >= 0) & (i + 3 <= NX - 1)
+def _horner(c, u):
+    v = c[-1]
+    for k in range(len(c) - 2, -1, -1):
+        v = v * u + c[k]
+    return v
 
 
-def in_psi_range(psi):
-    j = np.floor((psi - SLO) / DS)
-    return (j - 2 >= 0) & (j + 3 <= NS - 1)
+def column_poly(tab, j, q, s):
+    """Coefficients in z of x-piece j for a column with psi-coordinate s in psi-piece q: c_n = sum_m A[j][n][m][q] s^m."""
+    return np.array([_horner(tab[j, n, :, q], s) for n in range(NDEG + 1)])
 
 
-def evaluate(tab, x, psi):
-    """T(x ; psi) by 6 x 6 Lagrange interpolation; NaN outside the table's interior."""
-    if not (np.isfinite(x) and np.isfinite(psi)) or not in_x_range(x) or not in_psi_range(psi):
+def label(tab, x_lcl, t_lcl):
+    """(psi, q) with T(x_lcl ; psi) = t_lcl on the table, or (nan, -1) when the parcel is outside it."""
+    if not (np.isfinite(x_lcl) and np.isfinite(t_lcl)) or not (XLO <= x_lcl <= XHI):
+        return np.nan, -1
+    psi0 = float(_rk4(x_lcl, t_lcl, X1000, LABEL_H)) if x_lcl != X1000 else float(t_lcl)
+    if not (EDGES[0] + LABEL_MARGIN <= psi0 <= EDGES[-1] - LABEL_MARGIN):
+        return np.nan, -1
+    q = psi_piece(psi0)
+    j = x_piece(x_lcl)
+    z = (x_lcl - x_mid(j)) * (2.0 / WX)
+    b = np.array([_horner(tab[j, :, m, q], z) for m in range(MDEG + 1)])      # polynomial in s at x = x_lcl
+    db = b[1:] * np.arange(1, MDEG + 1)
+    inv_h = 1.0 / psi_half(q)
+    psi = psi0
+    for _ in range(NEWTON_STEPS):
+        s = (psi - psi_mid(q)) * inv_h
+        psi = psi - (_horner(b, s) - t_lcl) / (_horner(db, s) * inv_h)
+    if not (abs(psi - psi0) <= LABEL_MARGIN):
+        return np.nan, -1
+    return psi, q
+
+
+def evaluate(tab, x, psi, q):
+    """T(x ; psi) for a label found by label(); NaN for x > XHI; dry continuation above the table top."""
+    if not np.isfinite(x) or x > XHI:
         return np.nan
-    ux = (x - XLO) / DX
-    i = int(np.floor(ux))
-    us = (psi - SLO) / DS
-    j = int(np.floor(us))
-    return float(lagrange6(ux - i) @ tab[i - 2:i + 4, j - 2:j + 4] @ lagrange6(us - j))
-
-
-def label(tab, x_lcl, t_lcl, max_iter=12):
-    """psi with T(x_lcl ; psi) = t_lcl: Newton from the first-order guess t_lcl + dT/dlnp * (ln 1000 - x_lcl), clamped
-    to the table's interior; returns NaN when x_lcl is outside or the root sits on the clamp."""
-    if not (np.isfinite(x_lcl) and np.isfinite(t_lcl)) or not in_x_range(x_lcl):
-        return np.nan
-    lo, hi = SLO + 2.0 * DS, SLO + DS * (NS - 3) - 1e-9
-    psi = min(max(t_lcl + float(_f(x_lcl, t_lcl)) * (X1000 - x_lcl), lo), hi)
-    ux = (x_lcl - XLO) / DX
-    i = int(np.floor(ux))
-    wx = lagrange6(ux - i)
-    for _ in range(max_iter):
-        us = (psi - SLO) / DS
-        j = int(np.floor(us))
-        col = wx @ tab[i - 2:i + 4, j - 2:j + 4]
-        fval = float(col @ lagrange6(us - j)) - t_lcl
-        dval = float(col @ dlagrange6(us - j)) / DS
-        step = fval / dval
-        new = min(max(psi - step, lo), hi)
-        done = abs(new - psi) < 1e-10
-        psi = new
-        if done:
-            break
-    if abs(evaluate(tab, x_lcl, psi) - t_lcl) > 1e-8:
-        return np.nan                                  # label outside the table: caller falls back to RK4
-    return psi
+    s = (psi - psi_mid(q)) * (1.0 / psi_half(q))
+    if x < XLO:
+        t_top = _horner(column_poly(tab, NPX - 1, q, s), -1.0)
+        return float(t_top * np.exp(th.KAPPA * (x - XLO)))
+    j = x_piece(x)
+    z = (x - x_mid(j)) * (2.0 / WX)
+    return float(_horner(column_poly(tab, j, q, s), z))
 
 
 def moist_lapse_family(pressure, parcel_temperature, parcel_pressure=None):
@@ -146,16 +169,15 @@ def moist_lapse_family(pressure, parcel_temperature, parcel_pressure=None):
     if parcel_pressure is None:
         parcel_pressure = p[0]
     tab = table()
-    psi = label(tab, np.log(parcel_pressure), parcel_temperature) if parcel_pressure > 0 else np.nan
-    out = np.full(p.shape, np.nan)
+    psi, q = label(tab, np.log(parcel_pressure), parcel_temperature) if parcel_pressure > 0 else (np.nan, -1)
     if not np.isnan(psi):
         with np.errstate(invalid='ignore', divide='ignore'):
             x = np.log(p)
         ok = ~np.isnan(p)
-        vals = np.array([evaluate(tab, xx, psi) if o else np.nan for xx, o in zip(x, ok)])
-        out = vals
-        out[p == parcel_pressure] = parcel_temperature
+        vals = np.array([evaluate(tab, xx, psi, q) if o else np.nan for xx, o in zip(x, ok)])
+        vals[p == parcel_pressure] = parcel_temperature
         if not np.any(ok & np.isnan(vals)):
-            return out
-    # any level (or the label) outside the table: the whole parcel takes the RK4 mode, as the device fix-up pass does
+            return vals
+    # the label or a level (p > 1100 hPa) outside the table: the whole parcel takes the RK4 mode, as the device fix-up
+    # pass does
     return th.moist_lapse_rk4(p, parcel_temperature, parcel_pressure)

@@ -76,8 +76,12 @@ class XParcelError(RuntimeError):
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
 # translation units: the ABI + small kernels, and k_cape_cin once per (dtype, moist mode) -- see csrc/xp_cape_tu.hip
+# The family-mode kernels (mode 2) run as ONE 1024-thread workgroup per CU: the adiabat-family coefficient table (46.7 KB)
+# is staged into LDS next to the e_s / ln tables and the per-thread scan slots (157.5 of the CU's 160 KB).
+FAMILY_THREADS = int(os.environ.get('XP_FAMILY_THREADS', '1024'))
 UNITS = [('xparcel', 'xparcel.hip', [])] + [
-    (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}']) for t in ('double', 'float') for m in (0, 1, 2)]
+    (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}'] + ([f'-DXP_CAPE_THREADS={FAMILY_THREADS}'] if m == 2 else []))
+    for t in ('double', 'float') for m in (0, 1, 2)]
 
 
 def build(force=False, verbose=False, jobs=None):

@@ -400,110 +400,151 @@ struct Moist {
 };
 
 // ---- "adiabat family" exact mode -----------------------------------------------------------------------------
-// The solutions of the pseudo-adiabat ODE tabulated once, TAB[i][j] = T(X_i ; psi_j) with X_i = ln 30 + i*0.028 and
-// psi_j = 215 K + j*0.5 K the adiabat's temperature at 1000 hPa (built by xp_init: RK4 with 8 substeps per
-// interval, ~1e-11 K), and interpolated 6 x 6 (Lagrange): within 1.4e-6 K of the ODE (the RK4 stepper: 2e-5 K),
-// at ~55 instead of ~170 fp64 instructions per level.  The 213 KB table lives in global memory (L2-resident: every
-// wavefront reads the same rows); a column keeps its six psi-weights and a sliding window of six psi-collapsed
-// ln p-nodes in registers, so a level costs six FMAs plus, about every other level, one new 48-byte row segment.
-// A label or level outside the table marks the column `bad`; such columns are redone by the RK4 kernel.
-constexpr double FAM_XLO = 3.4011973816621555;   // ln 30
-constexpr double FAM_DX = 0.028, FAM_SLO = 215.0, FAM_DS = 0.5, FAM_X1000 = 6.907755278982137;
-constexpr int FAM_NX = 133, FAM_NS = 201, FAM_SUB = 8;
-
-XP_DEV void lagrange6(double t, double *w) {
-    double a = t + 2.0, b = t + 1.0, d = t - 1.0, e = t - 2.0, g = t - 3.0;
-    double ab = a * b, de = d * e, tg = t * g, bt = b * t, eg = e * g, ad = a * d;
-    w[0] = (-1.0 / 120.0) * (bt * de * g);
-    w[1] = (1.0 / 24.0) * (a * t * de * g);
-    w[2] = (-1.0 / 12.0) * (ab * de * g);
-    w[3] = (1.0 / 12.0) * (ab * t * eg);
-    w[4] = (-1.0 / 24.0) * (ab * t * d * g);
-    w[5] = (1.0 / 120.0) * (ab * t * de);
-    (void)tg; (void)ad;
-}
+// The one-parameter family of solutions of the pseudo-adiabat ODE, T(x ; psi) with x = ln p and psi = the adiabat's
+// temperature at 1000 hPa, stored once as a piecewise polynomial (specification: oracle/family.py; built by xp_init):
+//     x-pieces j < 8   : [XHI - 0.5 (j + 1), XHI - 0.5 j], XHI = ln 1100        (1100 ... ~20 hPa)
+//     psi-pieces q < 9 : [EDGES[q], EDGES[q + 1]], 215 ... 312 K, narrower towards the warm end
+//     T = sum_n sum_m A[j][n][m][q] z^n s^m,  z, s in [-1, 1] the piece-local coordinates,  n, m <= 8
+// within 7.5e-7 K of the ODE (the RK4 stepper: 2e-5 K).  A column finds its label once (one coarse RK4 march from the
+// LCL to 1000 hPa, then three Newton steps on the table inside the psi-piece the coarse label falls in), collapses the
+// psi direction of its current x-piece into nine coefficients held in registers, and from then on a level costs one
+// Horner evaluation (~14 fp64 instructions instead of ~155 for an RK4 step) -- no memory access in the level loop.
+// Moving into the next x-piece (every ~0.5 in ln p, i.e. 5-6 times per column) reloads the nine coefficients: 81
+// reads whose addresses differ between the lanes of a wavefront only in q (9 adjacent doubles per (j, n, m): a broadcast
+// plus adjacent banks when the table sits in LDS, one or two cache lines per instruction when it is read from L2 --
+// whatever the lanes' labels are, unlike a per-lane table walk).
+// Above the table top the adiabat continues dry (e_s / p < 1e-6 there).  A label or LCL outside the table marks the
+// column `bad`; such columns are redone by the RK4 kernel.
+constexpr double FAM_XHI = 7.003065458786462;    // ln 1100
+constexpr double FAM_WX = 0.5, FAM_X1000 = 6.907755278982137;
+constexpr int FAM_NPX = 8, FAM_ND = 8, FAM_MD = 8, FAM_NPS = 9;
+constexpr double FAM_XLO = FAM_XHI - FAM_WX * FAM_NPX;
+constexpr int FAM_COEFS = FAM_NPX * (FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS;
+constexpr int FAM_SIZE = FAM_COEFS + 2 * FAM_NPS;         // + psi-piece centres and 1 / half-widths (appended by the host)
+constexpr double FAM_LABEL_H = 0.25, FAM_MARGIN = 0.05;
+constexpr double FAM_PSI_LO = 215.0, FAM_PSI_HI = 312.0;
+#define XP_FAM_EDGES {215.0, 245.0, 262.0, 275.0, 285.0, 293.0, 299.0, 304.0, 308.5, 312.0}
 
 struct Family {
-    const double *tab;
-    double ws[6];          // Lagrange weights in psi (fixed per column)
-    double v[6];           // psi-collapsed table values at ln p-nodes iw .. iw+5
-    int jb, iw;            // first psi column / first ln p row of the stencils
+    const double *tab;     // coefficient table [j][n][m][q], then centre[q], 1 / half-width[q]
+    double c[FAM_ND + 1];  // the column's polynomial in z on x-piece jx
+    double m4;             // z = 4 x + m4
+    double s;              // the label's coordinate in psi-piece q
+    int jx, q;
     bool bad;
 
-    XP_DEV double row(int i) const {
-        const double *r = tab + (int64_t)i * FAM_NS + jb;
-        return ws[0] * r[0] + ws[1] * r[1] + ws[2] * r[2] + ws[3] * r[3] + ws[4] * r[4] + ws[5] * r[5];
+    XP_DEV static int psi_piece(double psi) {
+        return (int)(psi >= 245.0) + (int)(psi >= 262.0) + (int)(psi >= 275.0) + (int)(psi >= 285.0) + (int)(psi >= 293.0) +
+               (int)(psi >= 299.0) + (int)(psi >= 304.0) + (int)(psi >= 308.5);
     }
-    // label psi of the adiabat through (x_lcl, t_lcl): quasi-Newton on the interpolant (secant slope of the two
-    // central psi-nodes), converged to 1e-10 K; outside the table -> bad
-    XP_DEV void start(const double *table, double x_lcl, double t_lcl, double slope_guess) {
-        tab = table; bad = false; iw = 0x7fffffff; jb = 0;
-        for (int k = 0; k < 6; ++k) { ws[k] = 0.0; v[k] = qnan(); }
-        double ux = (x_lcl - FAM_XLO) * (1.0 / FAM_DX);
-        double fi = floor(ux);
-        if (!(fi - 2.0 >= 0.0 && fi + 3.0 <= (double)(FAM_NX - 1)) || isnan_(t_lcl)) { bad = true; return; }
-        int i = (int)fi;
-        double wx[6]; lagrange6(ux - fi, wx);
-        const double lo = FAM_SLO + 2.0 * FAM_DS, hi = FAM_SLO + FAM_DS * (double)(FAM_NS - 3) - 1e-9;
-        double psi = fmin(fmax(t_lcl + slope_guess * (FAM_X1000 - x_lcl), lo), hi);
-        double col[6] = {0, 0, 0, 0, 0, 0};
-        int jc = -1000;
-        double resid = qnan();
-        for (int it = 0; it < 16; ++it) {
-            double us = (psi - FAM_SLO) * (1.0 / FAM_DS);
-            double fj = floor(us);
-            int j = (int)fj;
-            if (j != jc) {                                   // (re)load the 6 x 6 block, collapse the ln p direction
-                jc = j;
-                const double *blk = tab + (int64_t)(i - 2) * FAM_NS + (j - 2);
-#define XP_FAM_COL(A)                                                                                              \
-                {                                                                                                  \
-                    double c = wx[0] * blk[A];                                                                     \
-                    c = __builtin_fma(wx[1], blk[FAM_NS + A], c);                                                  \
-                    c = __builtin_fma(wx[2], blk[2 * FAM_NS + A], c);                                              \
-                    c = __builtin_fma(wx[3], blk[3 * FAM_NS + A], c);                                              \
-                    c = __builtin_fma(wx[4], blk[4 * FAM_NS + A], c);                                              \
-                    c = __builtin_fma(wx[5], blk[5 * FAM_NS + A], c);                                              \
-                    col[A] = c;                                                                                    \
-                    asm volatile("" ::: "memory");   /* six loads in flight at a time, not thirty-six */            \
-                }
-                XP_FAM_COL(0) XP_FAM_COL(1) XP_FAM_COL(2) XP_FAM_COL(3) XP_FAM_COL(4) XP_FAM_COL(5)
-#undef XP_FAM_COL
-            }
-            double w6[6]; lagrange6(us - fj, w6);
-            double f = -t_lcl;
-            for (int a = 0; a < 6; ++a) f = __builtin_fma(col[a], w6[a], f);
-            resid = f;
-            double df = (col[3] - col[2]) * (1.0 / FAM_DS);
-            double nw = fmin(fmax(psi - fdiv(f, df), lo), hi);
-            bool done = fabs(nw - psi) < 1e-10;
-            psi = nw;
-            if (done) break;
+    XP_DEV static double x_mid(int j) { return FAM_XHI - FAM_WX * ((double)j + 0.5); }
+    // c_n = sum_m A[j][n][m][q] s^m: nine reads in flight at a time
+    XP_DEV void load_piece(int j) {
+        const double *a = tab + (size_t)(j * ((FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS) + q);
+#pragma unroll
+        for (int n = 0; n <= FAM_ND; ++n) {
+            const double *r = a + n * ((FAM_MD + 1) * FAM_NPS);
+            double v = r[FAM_MD * FAM_NPS];
+#pragma unroll
+            for (int m = FAM_MD - 1; m >= 0; --m) v = __builtin_fma(v, s, r[m * FAM_NPS]);
+            asm volatile("" : "+v"(v) : : "memory");     // this row is finished before the next row's reads are issued
+            c[n] = v;
         }
-        // the last residual was taken one (tiny) step before the final psi: |f| <= 1e-8 still certifies the root
-        if (!(fabs(resid) <= 1e-8)) { bad = true; return; }
-        double us = (psi - FAM_SLO) * (1.0 / FAM_DS);
-        double fj = floor(us);
-        jb = (int)fj - 2;
-        lagrange6(us - fj, ws);
+        jx = j;
+        m4 = -(2.0 / FAM_WX) * x_mid(j);
     }
-    // temperature of the column's adiabat at ln p = X (levels come with decreasing X)
-    XP_DEV double at(double X) {
-        double ux = (X - FAM_XLO) * (1.0 / FAM_DX);
-        double fi = floor(ux);
-        bool inside = (fi - 2.0 >= 0.0) && (fi + 3.0 <= (double)(FAM_NX - 1));
-        if (!inside) { if (!isnan_(X)) bad = true; return qnan(); }
-        if (bad) return qnan();
-        int want = (int)fi - 2;
-        if (want > iw || iw - want > 6) iw = want + 6;     // first use, or a jump past the window: refill by sliding
+    XP_DEV double horner(double z) const {
+        double v = c[FAM_ND];
+#pragma unroll
+        for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, c[n]);
+        return v;
+    }
+    // label of the adiabat through the LCL (x_lcl = ln p_lcl, t_lcl) and the coefficients of the x-piece the LCL is in
+    XP_DEV void start(const double *table, const double *es, double p_lcl, double x_lcl, double t_lcl) {
+        tab = table; jx = 0; q = 0; s = 0.0; m4 = 0.0;
+        bad = !(x_lcl >= FAM_XLO && x_lcl <= FAM_XHI) || isnan_(t_lcl);
+        // coarse label: RK4 to ln 1000 in steps <= 0.25
+        double dx = FAM_X1000 - x_lcl;
+        int ns = (int)ceil(fabs(dx) * (1.0 / FAM_LABEL_H) - 1e-12);
+        ns = ns < 1 ? 1 : ns;
+        ns = bad ? 1 : ns;
+        double h = bad ? 0.0 : dx * frcp((double)ns);
+        double qh = 0.5 * h;                                  // |qh| <= 0.125: exp by its Taylor series to qh^10 (< 1e-17)
+        double rh = 2.755731922398589e-07;
+        rh = __builtin_fma(rh, qh, 2.7557319223985893e-06);
+        rh = __builtin_fma(rh, qh, 2.48015873015873e-05);
+        rh = __builtin_fma(rh, qh, 1.984126984126984e-04);
+        rh = __builtin_fma(rh, qh, 1.388888888888889e-03);
+        rh = __builtin_fma(rh, qh, 8.333333333333333e-03);
+        rh = __builtin_fma(rh, qh, 4.1666666666666664e-02);
+        rh = __builtin_fma(rh, qh, 1.6666666666666666e-01);
+        rh = __builtin_fma(rh, qh, 0.5);
+        rh = __builtin_fma(rh, qh, 1.0);
+        rh = __builtin_fma(rh, qh, 1.0);
+        double t = t_lcl, ps = p_lcl;
 #pragma nounroll
-        while (iw > want) {                                // slide down one node at a time (six loads each)
-            --iw;
-            v[5] = v[4]; v[4] = v[3]; v[3] = v[2]; v[2] = v[1]; v[1] = v[0];
-            v[0] = row(iw);
+        for (int k = 0; k < ns; ++k) {
+            double pm = ps * rh, pe = pm * rh;
+            double k1 = dt_dlnp(es, ps, t, false);
+            double k2 = dt_dlnp(es, pm, t + 0.5 * h * k1, false);
+            double k3 = dt_dlnp(es, pm, t + 0.5 * h * k2, false);
+            double k4 = dt_dlnp(es, pe, t + h * k3, false);
+            t = t + (h * (1.0 / 6.0)) * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+            ps = pe;
         }
-        double wx[6]; lagrange6(ux - fi, wx);
-        return wx[0] * v[0] + wx[1] * v[1] + wx[2] * v[2] + wx[3] * v[3] + wx[4] * v[4] + wx[5] * v[5];
+        const double psi0 = t;
+        if (!(psi0 >= FAM_PSI_LO + FAM_MARGIN && psi0 <= FAM_PSI_HI - FAM_MARGIN)) bad = true;
+        q = bad ? 0 : psi_piece(psi0);
+        const double mid = tab[FAM_COEFS + q], inv_h = tab[FAM_COEFS + FAM_NPS + q];
+        double u = __builtin_fma(-(1.0 / FAM_WX), x_lcl, FAM_XHI * (1.0 / FAM_WX));
+        int j0 = bad ? 0 : (int)u;
+        j0 = j0 > FAM_NPX - 1 ? FAM_NPX - 1 : j0;
+        // Newton on the table inside piece q: T(x_lcl ; s) = sum_m b_m s^m with b_m = sum_n A[j0][n][m][q] z^n, value and
+        // derivative by one Horner sweep from m = 8 down; b_m is rebuilt from the table in every sweep instead of being
+        // kept -- nine doubles less at a point of high register pressure
+        const double z = bad ? 0.0 : (x_lcl - x_mid(j0)) * (2.0 / FAM_WX);
+        const double *a = tab + (size_t)(j0 * ((FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS) + q);
+        double psi = psi0;
+#pragma nounroll
+        for (int it = 0; it < 3; ++it) {
+            double sc = (psi - mid) * inv_h;
+            double val = 0.0, der = 0.0;
+#pragma unroll
+            for (int m = FAM_MD; m >= 0; --m) {
+                double v = a[(FAM_ND * (FAM_MD + 1) + m) * FAM_NPS];
+#pragma unroll
+                for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[(n * (FAM_MD + 1) + m) * FAM_NPS]);
+                asm volatile("" : "+v"(v) : : "memory");
+                der = __builtin_fma(der, sc, val);
+                val = __builtin_fma(val, sc, v);
+            }
+            psi = psi - fdiv(val - t_lcl, der * inv_h);
+        }
+        if (!(fabs(psi - psi0) <= FAM_MARGIN)) bad = true;
+        s = bad ? 0.0 : (psi - mid) * inv_h;
+        load_piece(j0);
+    }
+    // temperature of the column's adiabat at ln p = X (X <= x_lcl; levels normally come with decreasing X)
+    XP_DEV double at(double X) {
+        double u = __builtin_fma(-(1.0 / FAM_WX), X, FAM_XHI * (1.0 / FAM_WX));     // (XHI - X) / WX
+        int jn = (int)u;                                                            // NaN -> 0
+        double dry = 1.0;
+        bool move = (jn != jx) && !bad;
+        if (__builtin_amdgcn_ballot_w64(move) != 0ull) {                            // rare: another x-piece, or off the table
+            if (move && !isnan_(X)) {
+                if (u < 0.0) bad = true;                                            // p > 1100 hPa
+                else {
+                    bool top = jn > FAM_NPX - 1;                                    // above the table top: dry continuation
+                    int j = top ? FAM_NPX - 1 : jn;
+                    if (j != jx) load_piece(j);
+                    if (top) dry = fexp(KAPPA * (X - FAM_XLO));
+                }
+            }
+        }
+        double z = __builtin_fma(2.0 / FAM_WX, X, m4);
+        z = (dry != 1.0) ? -1.0 : z;
+        double v = horner(z) * dry;
+        return bad ? qnan() : v;
     }
 };
 

@@ -41,7 +41,7 @@ struct CapeArgs {
     int off32;                            // 1: the three views share strides and a column's byte offset within a level fits 32 bits
     Tables tb;
     const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
-    const double *fam_tab;                // adiabat-family table [FAM_NX][FAM_NS] (family mode)
+    const double *fam_tab;                // adiabat-family table (xp::Family; family mode)
     int32_t *flags;                       // family mode: 1 = column must be redone by the RK4 kernel
     int only_flagged;                     // RK4 fix-up pass: process flagged columns only
     ScalarsOut s;
@@ -148,7 +148,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
-__global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
     // with 24 B of scratch or none, still a net gain); profile output and the family mode stay at 3 waves (168).  The
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE) ? 3 : (PMO
     // tests/test_kernel_resources.py checks what comes out.
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
+    // family mode: the coefficient table lives in LDS too (46.7 KB; read 81 doubles at a time by lanes that differ only in
+    // their psi-piece: broadcast + adjacent banks, conflict-free, ~100 cycles instead of an L2 round trip per batch)
+    __shared__ double s_fam[FAMILY ? FAM_SIZE : 1];
+    if (FAMILY) for (int i = threadIdx.x; i < FAM_SIZE; i += blockDim.x) s_fam[i] = a.fam_tab[i];
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a.only_flagged) {                                                  // fix-up pass: most blocks have nothing to do
         int need = (c < a.ncol) ? a.flags[c] : 0;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, ((MODE == 2 || PROFILE) ? 3 : (PMO
     sc.slot[SL_LCL_T * SLOT_STRIDE] = a.vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
     Moist m;
     Family fam;
-    if (FAMILY) fam.start(a.fam_tab, x_lcl, l.t, dt_dlnp_e(l.p, l.t, es_tab(es, l.t)));
+    if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t);
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int jout = 0;                                                           // profile row

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -119,33 +120,98 @@ struct Stager {
     }
 };
 
-// adiabat-family table (xp::Family; specification restated independently in oracle/family.py): for every label psi_j
-// march MetPy's pseudo-adiabat from 1000 hPa to every ln p node by classical RK4, 8 substeps per interval
+// adiabat-family table (xp::Family; specification restated independently in oracle/family.py): the pseudo-adiabat
+// through every psi-node (Chebyshev points of every psi-piece) is marched from 1000 hPa through the x-nodes (Chebyshev
+// points of every x-piece, in order of distance) by classical RK4 with steps <= 1/80, and every (x-piece, psi-piece)
+// block of 9 x 9 values is turned into the monomial coefficients of its interpolant (long double elimination).
 double fam_dt_dlnp(double x, double t) {
     double p = std::exp(x), e = 6.112 * std::exp(17.67 * (t - 273.15) / (t - 29.65)), pe = p - e;
     double num = xp::RD * t * pe + xp::LV * xp::EPS * e;
     double den = xp::CP_D * xp::RD * t * t * pe + xp::LV * xp::LV * xp::EPS * xp::EPS * e;
     return xp::RD * t * t * num / den;
 }
+double fam_march(double x, double t, double x1) {
+    int n = (int)std::ceil(std::fabs(x1 - x) / 0.0125 - 1e-12);
+    if (n < 1) n = 1;
+    const double h = (x1 - x) / n;
+    for (int s = 0; s < n; ++s) {
+        double k1 = fam_dt_dlnp(x, t);
+        double k2 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
+        double k3 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
+        double k4 = fam_dt_dlnp(x + h, t + h * k3);
+        t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
+        x = x + h;
+    }
+    return t;
+}
+// monomial coefficients of the polynomial through (u_k, y_k), k < n
+void fam_interpolant(int n, const double *u, const double *y, double *c) {
+    using LD = long double;
+    std::vector<LD> A((size_t)n * (n + 1));
+    auto at = [&](int r, int col) -> LD & { return A[(size_t)r * (n + 1) + col]; };
+    for (int k = 0; k < n; ++k) {
+        LD v = 1.0L;
+        for (int i = 0; i < n; ++i) { at(k, i) = v; v *= (LD)u[k]; }
+        at(k, n) = (LD)y[k];
+    }
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < n; ++r) if (fabsl(at(r, col)) > fabsl(at(piv, col))) piv = r;
+        for (int i = 0; i <= n; ++i) std::swap(at(col, i), at(piv, i));
+        for (int r = 0; r < n; ++r) {
+            if (r == col) continue;
+            LD f = at(r, col) / at(col, col);
+            for (int i = col; i <= n; ++i) at(r, i) -= f * at(col, i);
+        }
+    }
+    for (int i = 0; i < n; ++i) c[i] = (double)(at(i, n) / at(i, i));
+}
+const double kFamEdges[xp::FAM_NPS + 1] = XP_FAM_EDGES;
+// the psi-piece centres and reciprocal half-widths the device reads behind the coefficients
+void fam_append_pieces(double *tab) {
+    for (int q = 0; q < xp::FAM_NPS; ++q) {
+        tab[xp::FAM_COEFS + q] = 0.5 * (kFamEdges[q] + kFamEdges[q + 1]);
+        tab[xp::FAM_COEFS + xp::FAM_NPS + q] = 1.0 / (0.5 * (kFamEdges[q + 1] - kFamEdges[q]));
+    }
+}
 void build_family_table(double *tab) {
-    const int i_up = (int)std::floor((xp::FAM_X1000 - xp::FAM_XLO) / xp::FAM_DX);
-    for (int j = 0; j < xp::FAM_NS; ++j)
-        for (int dir = -1; dir <= 1; dir += 2) {
-            double t = xp::FAM_SLO + xp::FAM_DS * j, x = xp::FAM_X1000;
-            for (int i = (dir < 0 ? i_up : i_up + 1); i >= 0 && i < xp::FAM_NX; i += dir) {
-                double x1 = xp::FAM_XLO + xp::FAM_DX * i, h = (x1 - x) / xp::FAM_SUB;
-                for (int s = 0; s < xp::FAM_SUB; ++s) {
-                    double k1 = fam_dt_dlnp(x, t);
-                    double k2 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k1);
-                    double k3 = fam_dt_dlnp(x + 0.5 * h, t + 0.5 * h * k2);
-                    double k4 = fam_dt_dlnp(x + h, t + h * k3);
-                    t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
-                    x = x + h;
-                }
-                x = x1;
-                tab[(size_t)i * xp::FAM_NS + j] = t;
+    const int NN = xp::FAM_ND + 1, MM = xp::FAM_MD + 1, NXN = xp::FAM_NPX * NN, NSN = xp::FAM_NPS * MM;
+    const double pi = 3.14159265358979323846;
+    std::vector<double> un(NN), um(MM), xs(NXN), ps(NSN), vals((size_t)NXN * NSN);
+    for (int k = 0; k < NN; ++k) un[k] = std::cos(pi * (k + 0.5) / NN);
+    for (int k = 0; k < MM; ++k) um[k] = std::cos(pi * (k + 0.5) / MM);
+    for (int j = 0; j < xp::FAM_NPX; ++j)
+        for (int k = 0; k < NN; ++k) xs[j * NN + k] = (xp::FAM_XHI - xp::FAM_WX * (j + 0.5)) + 0.5 * xp::FAM_WX * un[k];
+    for (int q = 0; q < xp::FAM_NPS; ++q)
+        for (int k = 0; k < MM; ++k)
+            ps[q * MM + k] = 0.5 * (kFamEdges[q] + kFamEdges[q + 1]) + 0.5 * (kFamEdges[q + 1] - kFamEdges[q]) * um[k];
+    for (int side = 0; side < 2; ++side) {
+        std::vector<int> order;
+        for (int i = 0; i < NXN; ++i) if ((side == 0) == (xs[i] <= xp::FAM_X1000)) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(xs[a] - xp::FAM_X1000) < std::fabs(xs[b] - xp::FAM_X1000); });
+        for (int c = 0; c < NSN; ++c) {
+            double x = xp::FAM_X1000, t = ps[c];
+            for (int i : order) {
+                if (xs[i] != x) { t = fam_march(x, t, xs[i]); x = xs[i]; }
+                vals[(size_t)i * NSN + c] = t;
             }
         }
+    }
+    std::vector<double> a((size_t)NN * MM), col(NN), cf(NN), row(MM), rf(MM);
+    for (int j = 0; j < xp::FAM_NPX; ++j)
+        for (int q = 0; q < xp::FAM_NPS; ++q) {
+            for (int m = 0; m < MM; ++m) {
+                for (int k = 0; k < NN; ++k) col[k] = vals[(size_t)(j * NN + k) * NSN + (q * MM + m)];
+                fam_interpolant(NN, un.data(), col.data(), cf.data());
+                for (int n = 0; n < NN; ++n) a[(size_t)n * MM + m] = cf[n];
+            }
+            for (int n = 0; n < NN; ++n) {
+                for (int m = 0; m < MM; ++m) row[m] = a[(size_t)n * MM + m];
+                fam_interpolant(MM, um.data(), row.data(), rf.data());
+                for (int m = 0; m < MM; ++m) tab[(((size_t)j * NN + n) * MM + m) * xp::FAM_NPS + q] = rf[m];
+            }
+        }
+    fam_append_pieces(tab);
 }
 
 int check_view(const xp_view *v, const char *name) {
@@ -168,6 +234,13 @@ int stage_view(Stager &st, const xp_view *v, xp::View *out) {
     out->data = d; out->ls = v->lev_stride; out->cs = v->col_stride;
     return 0;
 }
+// every entry point switches to the library's device for its duration and leaves the calling thread's current device
+// as it found it (the caller -- torch, say -- may be working on another one)
+struct DevGuard {
+    int prev = -1;
+    DevGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 int ensure_init() {
     if (!g.init) return fail(XP_E_NOT_INIT, "xp_init() has not been called");
     hipError_t e = hipSetDevice(g.device);
@@ -287,6 +360,11 @@ int xp_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(XP_E_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(XP_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    DevGuard dg_;
+    if (g.init && g.device != device) {                      // moving to another device: nothing queued on the old one may
+        HIP_TRY(hipSetDevice(g.device));                     // still be reading the buffers freed below
+        HIP_TRY(hipDeviceSynchronize());
+    }
     HIP_TRY(hipSetDevice(device));
     if (g.init && g.device != device && g.tables) {
         // tables live on the old device; drop them, the caller reloads
@@ -302,7 +380,7 @@ int xp_init(int device) {
     }
     if (g.init && g.device != device && g.fam_tab) { (void)hipFree(g.fam_tab); g.fam_tab = nullptr; }
     if (!g.fam_tab) {
-        if (g.fam_host.empty()) { g.fam_host.resize((size_t)xp::FAM_NX * xp::FAM_NS); build_family_table(g.fam_host.data()); }
+        if (g.fam_host.empty()) { g.fam_host.resize((size_t)xp::FAM_SIZE); build_family_table(g.fam_host.data()); }
         HIP_TRY(hipMalloc((void **)&g.fam_tab, sizeof(double) * g.fam_host.size()));
         HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
     }
@@ -312,12 +390,19 @@ int xp_init(int device) {
 }
 
 int xp_set_tables(const xp_tables *t) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g.mu);
     if (!t || !t->index || !t->adiabats || t->n_pressure < 2 || t->n_temperature < 2 || t->n_adiabat < 1)
         return fail(XP_E_ARG, "xp_set_tables: bad tables");
-    if (g.tables) { (void)hipFree(g.tb_index); (void)hipFree(g.tb_adiabats); g.tables = false; }
+    if (g.tables) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(g.tb_index); (void)hipFree(g.tb_adiabats); g.tables = false; }
+    {   // an index entry beyond n_adiabat would send Moist::start outside the adiabat array
+        const uint16_t *ix = (const uint16_t *)t->index;
+        size_t n_ix = (size_t)t->n_pressure * (size_t)t->n_temperature;
+        for (size_t i = 0; i < n_ix; ++i)
+            if ((int64_t)ix[i] > t->n_adiabat) return fail(XP_E_ARG, "xp_set_tables: index entry %u > n_adiabat %lld", (unsigned)ix[i], (long long)t->n_adiabat);
+    }
     size_t ib = (size_t)t->n_pressure * (size_t)t->n_temperature * 2, ab = (size_t)t->n_adiabat * (size_t)t->n_pressure * 4;
     HIP_TRY(hipMalloc(&g.tb_index, ib));
     HIP_TRY(hipMalloc(&g.tb_adiabats, ab));
@@ -332,25 +417,29 @@ int xp_set_tables(const xp_tables *t) {
 int xp_tables_loaded(void) { return g.tables ? 1 : 0; }
 
 int xp_family_table(double *out, int64_t *n_lnp, int64_t *n_label) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
-    if (n_lnp) *n_lnp = xp::FAM_NX;
-    if (n_label) *n_label = xp::FAM_NS;
-    if (out) memcpy(out, g.fam_host.data(), sizeof(double) * g.fam_host.size());
+    if (n_lnp) *n_lnp = xp::FAM_COEFS / xp::FAM_NPS;
+    if (n_label) *n_label = xp::FAM_NPS;
+    if (out) memcpy(out, g.fam_host.data(), sizeof(double) * xp::FAM_COEFS);
     return XP_OK;
 }
 int xp_set_family_table(const double *tab, int64_t n_lnp, int64_t n_label) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
-    if (!tab || n_lnp != xp::FAM_NX || n_label != xp::FAM_NS) return fail(XP_E_ARG, "xp_set_family_table: wrong shape");
+    if (!tab || n_lnp != xp::FAM_COEFS / xp::FAM_NPS || n_label != xp::FAM_NPS) return fail(XP_E_ARG, "xp_set_family_table: wrong shape");
     std::lock_guard<std::mutex> lk(g.mu);
-    memcpy(g.fam_host.data(), tab, sizeof(double) * g.fam_host.size());
+    HIP_TRY(hipDeviceSynchronize());                         // kernels in flight may still read the old table
+    memcpy(g.fam_host.data(), tab, sizeof(double) * xp::FAM_COEFS);
     HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
     return XP_OK;
 }
 
 int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel, const xp_opts *o,
                 xp_scalars_out *scalars, xp_profile_out *profile, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     Stager st(stream);
@@ -384,6 +473,7 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
 
 int xp_select_parcel(const xp_view *p, const xp_view *t, const xp_view *td, const xp_parcel *parcel,
                      xp_scalars_out *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     Stager st(stream);
@@ -406,6 +496,7 @@ int xp_select_parcel(const xp_view *p, const xp_view *t, const xp_view *td, cons
 }
 
 int xp_mixed_layer(const xp_view *p, const xp_view *v, double depth, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure")) || (rc = check_view(v, "variable")) || (rc = same_shape(p, v, "pressure/variable"))) return rc;
@@ -424,6 +515,7 @@ int xp_mixed_layer(const xp_view *p, const xp_view *v, double depth, void *out, 
 
 int xp_lcl(int64_t n, int32_t dtype, int32_t mem, const void *pp, const void *pt, const void *ptd, void *lp, void *lt,
            void *ltv, int32_t *status, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if (n < 0 || !pp || !pt || !ptd) return fail(XP_E_ARG, "xp_lcl: null input");
@@ -443,6 +535,7 @@ int xp_lcl(int64_t n, int32_t dtype, int32_t mem, const void *pp, const void *pt
 }
 
 int xp_dry_lapse(const xp_view *p, const void *pt, const void *pp, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure"))) return rc;
@@ -463,6 +556,7 @@ int xp_dry_lapse(const xp_view *p, const void *pt, const void *pp, void *out, vo
 }
 
 int xp_moist_lapse(const xp_view *p, const void *pt, const void *pp, int32_t moist_mode, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure"))) return rc;
@@ -487,6 +581,7 @@ int xp_moist_lapse(const xp_view *p, const void *pt, const void *pp, int32_t moi
 
 int xp_parcel_profile(const xp_view *p, const void *pp, const void *pt, const void *ptd, int32_t moist_mode,
                       void *t_out, void *tv_out, void *lp, void *lt, void *ltv, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure"))) return rc;
@@ -513,6 +608,7 @@ int xp_parcel_profile(const xp_view *p, const void *pp, const void *pt, const vo
 
 int xp_lfc_el(const xp_view *p, const xp_view *par, const xp_view *env, const void *lcl_p, const void *lcl_t,
               xp_scalars_out *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure")) || (rc = check_view(par, "parcel_temperature")) || (rc = check_view(env, "temperature")) ||
@@ -535,6 +631,7 @@ int xp_lfc_el(const xp_view *p, const xp_view *par, const xp_view *env, const vo
 
 int xp_cape_cin_base(const xp_view *p, const xp_view *env, const xp_view *par, const void *lfc_p, const void *el_p,
                      const xp_opts *o, void *cape, void *cin, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure")) || (rc = check_view(par, "parcel_temperature")) || (rc = check_view(env, "temperature")) ||
@@ -558,6 +655,7 @@ int xp_cape_cin_base(const xp_view *p, const xp_view *env, const xp_view *par, c
 
 int xp_wet_bulb_temperature(const xp_view *p, const xp_view *t, const xp_view *td, int32_t moist_mode, void *out,
                             void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(td, "dewpoint")) ||
@@ -582,6 +680,7 @@ int xp_wet_bulb_temperature(const xp_view *p, const xp_view *t, const xp_view *t
 
 int xp_interp_level(const xp_view *coords, const xp_view *x, const void *at, int32_t at_is_scalar, int32_t log_coords,
                     void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(coords, "coords")) || (rc = check_view(x, "variable")) || (rc = same_shape(coords, x, "coords/variable"))) return rc;
@@ -602,6 +701,7 @@ int xp_interp_level(const xp_view *coords, const xp_view *x, const void *at, int
 }
 
 int xp_dewpoint_from_specific_humidity(const xp_view *p, const xp_view *t, const xp_view *q, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(q, "specific_humidity")) ||
@@ -622,6 +722,7 @@ int xp_dewpoint_from_specific_humidity(const xp_view *p, const xp_view *t, const
 }
 
 int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(x, "x")) || (rc = check_view(a, "a")) || (rc = same_shape(x, a, "x/a"))) return rc;
@@ -639,6 +740,7 @@ int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *ou
 }
 
 int xp_mixing_ratio(const xp_view *t, const xp_view *td, const xp_view *p, void *out, void *stream) {
+    DevGuard dg_;
     int rc = ensure_init();
     if (rc) return rc;
     if ((rc = check_view(t, "temperature")) || (rc = check_view(td, "dewpoint")) || (rc = check_view(p, "pressure")) ||

@@ -29,13 +29,22 @@ def _is_torch(x):
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+import threading as _threading
+
+_CTX = _threading.local()      # .device: the torch device of the call being assembled on this thread (None: host arrays)
+
+
+def _ctx_device():
+    return getattr(_CTX, 'device', None)
+
+
 class _Arr:
     """Uniform handle on a NumPy array or torch CUDA tensor, flattened to (nlev, ncol)."""
 
     def __init__(self, x, dtype=None, like=None):
         if _is_torch(x):
             if not x.is_cuda:
-                x = x.cuda()
+                x = x.to(_ctx_device() or 'cuda')
             if dtype is not None:
                 x = x.to(dtype=torch.float64 if dtype == np.float64 else torch.float32)
             elif x.dtype not in (torch.float32, torch.float64):
@@ -67,8 +76,9 @@ class _Arr:
 
 
 def _stream(dev):
+    """torch's current stream on the device the call's tensors live on (not on torch's current device)."""
     if dev and torch is not None:
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(_ctx_device()).cuda_stream)
     return C.c_void_p(0)
 
 
@@ -80,14 +90,17 @@ def _device_of(h):
 
 def _common(*xs):
     """Bring inputs to one dtype / one memory space; return handles + (nlev, ncol, hshape)."""
-    any_dev = any(_is_torch(x) and x.is_cuda for x in xs)
+    devs = [x.device for x in xs if _is_torch(x) and x.is_cuda]
+    any_dev = bool(devs)
+    assert all(d == devs[0] for d in devs), 'all device tensors of one call must live on the same GPU'
+    _CTX.device = devs[0] if any_dev else None
     f64 = any((_is_torch(x) and x.dtype == torch.float64) or
               (not _is_torch(x) and np.asarray(x).dtype != np.float32) for x in xs)
     dt = np.float64 if f64 else np.float32
     hs = []
     for x in xs:
         if any_dev and not _is_torch(x):
-            x = torch.as_tensor(np.asarray(x, dtype=dt)).cuda()
+            x = torch.as_tensor(np.asarray(x, dtype=dt)).to(devs[0])
         hs.append(_Arr(x, dtype=dt))
     return hs, dt, any_dev
 
@@ -115,7 +128,7 @@ def _vert_shape(h):
 def _per_col(x, ncol, dt, dev, like):
     """Per-column input (scalar or array of hshape) -> handle of ncol elements."""
     if _is_torch(x):
-        h = _Arr(x.reshape(-1), dtype=dt)
+        h = _Arr((x.to(like.t.device) if dev else x).reshape(-1), dtype=dt)
     else:
         a = np.asarray(x, dtype=dt).reshape(-1)
         if a.size == 1 and ncol != 1:
@@ -632,7 +645,8 @@ def storm_proxies(dat):
 
 
 def family_table():
-    """The adiabat-family table of moist='family' as a (n_lnp, n_label) float64 array (xp_family_table)."""
+    """The adiabat-family coefficient table of moist='family' as a (n_coef_rows, n_label_pieces) float64 array: rows are
+    (x-piece, power of z, power of s), C-order (xp_family_table)."""
     lib = L.init()
     n1, n2 = C.c_int64(), C.c_int64()
     L.check(lib.xp_family_table(None, C.byref(n1), C.byref(n2)))
@@ -644,4 +658,5 @@ def family_table():
 def set_family_table(table):
     """Replace the adiabat-family table (xp_set_family_table)."""
     t = np.ascontiguousarray(table, dtype=np.float64)
+    t = t.reshape(-1, t.shape[-1])
     L.check(L.init().xp_set_family_table(t.ctypes.data_as(C.c_void_p), C.c_int64(t.shape[0]), C.c_int64(t.shape[1])))
