@@ -1,11 +1,8 @@
-# A/B of library variants in one box: bench (c2) + c5 share per variant; usage: run_gpu_ab.sh "" _old ...
-for v in "$@"; do
-  export XPARCEL_LIB=$GRAFT_REPO_ROOT/xarray_parcel_amd/lib/libxparcel$v.so
-  for rep in 1 2; do
-  timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu 2>/dev/null | python -c "
-import sys,json
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('VARIANT', '[$v]', 'c2 kernel_ms', round(d['roofline']['kernel_ms'],4))"
-  done
-  timeout -k 10 600 python scripts/run_gpu_c5.py 2>&1 | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('VARIANT', '[$v]', {k:(round(v['kernel_ms'],2), v['indices_match_sample']) for k,v in d.items()})"
+# A/B of library builds: run_gpu_ab.sh <bench args> -- lib1.so lib2.so ...   (libs under xarray_parcel_amd/lib/)
+args=(); while [ "$1" != "--" ] && [ $# -gt 0 ]; do args+=("$1"); shift; done; shift
+for L in "$@"; do
+  export XPARCEL_LIB=$PWD/xarray_parcel_amd/lib/$L
+  echo "== $L"
+  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu "${args[@]}" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('kernel_ms', d['roofline']['kernel_ms'])"
+  bash scripts/run_gpu_pmc_mode.sh "${args[@]}" 2>&1 | grep -E "KERNEL.*(2|0), false|INSTS_VALU|VMEM_RD|WAIT_ANY|WAVE_CYCLES|INSTS_LDS|WRITE_SIZE" | head -8
 done

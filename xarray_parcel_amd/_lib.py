@@ -74,11 +74,12 @@ class XParcelError(RuntimeError):
         self.code = code
 
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC'] + os.environ.get('XP_EXTRA_DEFS', '').split()   # (A/B builds)
 # translation units: the ABI + small kernels, and k_cape_cin once per (dtype, moist mode) -- see csrc/xp_cape_tu.hip
-# The family-mode kernels (mode 2) run as ONE 1024-thread workgroup per CU: the adiabat-family coefficient table (46.7 KB)
-# is staged into LDS next to the e_s / ln tables and the per-thread scan slots (157.5 of the CU's 160 KB).
-FAMILY_THREADS = int(os.environ.get('XP_FAMILY_THREADS', '1024'))
+# The family-mode kernels (mode 2) run as ONE 768-thread workgroup per CU (3 wavefronts per SIMD): the adiabat-family
+# coefficient table (46.7 KB) is staged into LDS next to the e_s / ln tables and the per-thread scan slots (134 of the
+# CU's 160 KB).  1024 threads fit the LDS too (157.5 KB) but not the 128-VGPR budget that comes with them.
+FAMILY_THREADS = int(os.environ.get('XP_FAMILY_THREADS', '768'))
 UNITS = [('xparcel', 'xparcel.hip', [])] + [
     (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}'] + ([f'-DXP_CAPE_THREADS={FAMILY_THREADS}'] if m == 2 else []))
     for t in ('double', 'float') for m in (0, 1, 2)]

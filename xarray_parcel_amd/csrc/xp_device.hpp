@@ -430,7 +430,7 @@ struct Family {
     double c[FAM_ND + 1];  // the column's polynomial in z on x-piece jx
     double m4;             // z = 4 x + m4
     double s;              // the label's coordinate in psi-piece q
-    int jx, q;
+    int q;
     bool bad;
 
     XP_DEV static int psi_piece(double psi) {
@@ -450,7 +450,6 @@ struct Family {
             asm volatile("" : "+v"(v) : : "memory");     // this row is finished before the next row's reads are issued
             c[n] = v;
         }
-        jx = j;
         m4 = -(2.0 / FAM_WX) * x_mid(j);
     }
     XP_DEV double horner(double z) const {
@@ -461,7 +460,7 @@ struct Family {
     }
     // label of the adiabat through the LCL (x_lcl = ln p_lcl, t_lcl) and the coefficients of the x-piece the LCL is in
     XP_DEV void start(const double *table, const double *es, double p_lcl, double x_lcl, double t_lcl) {
-        tab = table; jx = 0; q = 0; s = 0.0; m4 = 0.0;
+        tab = table; q = 0; s = 0.0; m4 = 0.0;
         bad = !(x_lcl >= FAM_XLO && x_lcl <= FAM_XHI) || isnan_(t_lcl);
         // coarse label: RK4 to ln 1000 in steps <= 0.25
         double dx = FAM_X1000 - x_lcl;
@@ -524,25 +523,27 @@ struct Family {
         s = bad ? 0.0 : (psi - mid) * inv_h;
         load_piece(j0);
     }
-    // temperature of the column's adiabat at ln p = X (X <= x_lcl; levels normally come with decreasing X)
+    // temperature of the column's adiabat at ln p = X (X <= x_lcl; levels normally come with decreasing X).
+    // x-piece j holds z in (-1, 1]: the fast path only tests that (the piece index itself is recovered from m4 when a
+    // lane has to move, with the oracle's floor rule).
     XP_DEV double at(double X) {
-        double u = __builtin_fma(-(1.0 / FAM_WX), X, FAM_XHI * (1.0 / FAM_WX));     // (XHI - X) / WX
-        int jn = (int)u;                                                            // NaN -> 0
-        double dry = 1.0;
-        bool move = (jn != jx) && !bad;
-        if (__builtin_amdgcn_ballot_w64(move) != 0ull) {                            // rare: another x-piece, or off the table
-            if (move && !isnan_(X)) {
-                if (u < 0.0) bad = true;                                            // p > 1100 hPa
-                else {
-                    bool top = jn > FAM_NPX - 1;                                    // above the table top: dry continuation
-                    int j = top ? FAM_NPX - 1 : jn;
-                    if (j != jx) load_piece(j);
-                    if (top) dry = fexp(KAPPA * (X - FAM_XLO));
-                }
-            }
-        }
         double z = __builtin_fma(2.0 / FAM_WX, X, m4);
-        z = (dry != 1.0) ? -1.0 : z;
+        double dry = 1.0;
+        bool move = !(z > -1.0 && z <= 1.0) && !bad;                                // NaN X -> move (and nothing to do)
+        if (__builtin_amdgcn_ballot_w64(move) != 0ull) {                            // rare: another x-piece, or off the table
+            // every lane of the wavefront reloads -- the ones that stay put their current piece -- so that the nine
+            // coefficients are plainly overwritten instead of merged per lane (which would keep old and new alive together)
+            double u = __builtin_fma(-(1.0 / FAM_WX), X, FAM_XHI * (1.0 / FAM_WX)); // (XHI - X) / WX
+            bool go = move && !isnan_(X);
+            if (go && u < 0.0) { bad = true; go = false; }                          // p > 1100 hPa
+            int jn = (int)u;
+            bool top = go && jn > FAM_NPX - 1;                                      // above the table top: dry continuation
+            int jcur = (int)__builtin_rint(__builtin_fma(m4, 0.5, FAM_XHI * (1.0 / FAM_WX) - 0.5));
+            int j = go ? (jn > FAM_NPX - 1 ? FAM_NPX - 1 : jn) : jcur;
+            load_piece(j);
+            z = __builtin_fma(2.0 / FAM_WX, X, m4);
+            if (top) { dry = fexp(KAPPA * (X - FAM_XLO)); z = -1.0; }
+        }
         double v = horner(z) * dry;
         return bad ? qnan() : v;
     }
