@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """
-bench.py -- headline benchmark (BASELINE.json): column-profiles/s for surface_based_cape_cin on
-config c2, synthetic 64-level x 1024 x 1024 fp64 soundings, CAPE/CIN only, per GPU.
+bench.py -- headline benchmark (BASELINE.json): column-profiles/s for surface_based_cape_cin, per config.
 
-A "step" is one pass of the hot path (xp_cape_cin, surface parcel, exact moist mode, defaults of the
-reference: virtual-temperature correction on, log LCL interpolation) over the rank's 1024 x 1024
-columns, inputs already resident in HBM.  With N > 1 ranks (torchrun, one process per GPU) every rank
-owns its own 1024 x 1024 slab of a (N*1024) x 1024 grid (weak scaling, no data-path collective) and the
-per-column CAPE/CIN are gathered to rank 0 with one RCCL gather per step on a side stream.
+  --config c2 (default, the headline): synthetic 64-level x 1024 x 1024 fp64 soundings PER GPU, CAPE/CIN only.  With N > 1
+            ranks every rank owns its own slab of a (N*1024) x 1024 grid (weak scaling).
+  --config c4: ONE fixed 128-level x 8192 x 8192 fp32 grid, surface-based CAPE/CIN, cut into N contiguous y-slabs
+            (strong scaling: the 1/2/4/8-GPU curve of SURVEY.md 8e).
+  --config c5: ONE fixed 24-timestep x 100-level x 2048 x 2048 fp32 grid, most-unstable AND mixed-layer CAPE/CIN per
+            step, the flattened (time, y) axis cut into N slabs (strong scaling).
 
-Prints ONE JSON line on rank 0.  `roofline` is computed from HIP-event timings of the kernel launches
-inside the timed region; `cpu_baseline` times the CPU oracle (C restatement, OpenMP, all host cores) on
-a bounded sample of the same workload.
+A "step" is one pass of the hot path (xp_cape_cin through the C ABI; reference defaults: virtual-temperature
+correction on, log LCL interpolation) over the rank's columns, inputs already resident in HBM.  Columns are independent:
+no data-path collective; the per-column CAPE/CIN are gathered to rank 0 with one RCCL gather per step (per parcel) on a
+side stream.  (The reference's counterpart: dask chunks over the horizontal dims, pf.py:343-346, parcel_test.py:604.)
+
+Prints ONE JSON line on rank 0.  `roofline` is computed from HIP-event timings of the dominant kernel's launches inside
+the timed region; `cpu_baseline` times the CPU oracle (C restatement, OpenMP, all host cores) on a bounded sample of the
+same workload; `table_mode` (c2, one GPU) is the same step in the reference's shipping moist mode (its lookup tables,
+pf.py:525-607), measured after the headline's timed region.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -22,8 +29,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NLEV, NY, NX = 64, 1024, 1024
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (5.1-5.8 TB/s is what copy / triad kernels reach)
+MOIST_ID = {'exact': 0, 'table': 1, 'family': 2}
+PARCEL_ID = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2}
+CONFIGS = {
+    'c2': dict(nlev=64, nt=1, ny=1024, nx=1024, dtype='f64', parcels=('surface',), scaling='weak', seed=20250719,
+               what='synthetic 64-level x 1024 x 1024 f64 soundings per GPU'),
+    'c4': dict(nlev=128, nt=1, ny=8192, nx=8192, dtype='f32', parcels=('surface',), scaling='strong', seed=20250721,
+               what='one synthetic 128-level x 8192 x 8192 f32 grid cut into y-slabs'),
+    'c5': dict(nlev=100, nt=24, ny=2048, nx=2048, dtype='f32', parcels=('most_unstable', 'mixed_layer'), scaling='strong',
+               seed=20250722, what='one synthetic 24-timestep x 100-level x 2048 x 2048 f32 grid, (time, y) cut into slabs'),
+}
 
 
 def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
@@ -31,53 +47,54 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
     return 3 * nlev * itemsize + n_out * itemsize
 
 
-def measured_traffic(nlev, ny, nx, dtype):
-    """HBM bytes per launch from the rocprofv3 PMC pass committed under profiles/ (FETCH_SIZE / WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md prescribes; see the JSON's note).  bench.py cannot run the profiler on itself,
-    so this is the number measured on the same command at the time the profile was taken; None for any other shape."""
-    import glob
-    if (nlev, ny, nx, dtype) != (NLEV, NY, NX, 'f64'):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
-    if not files:
-        return None
-    try:
-        return float(json.load(open(files[-1]))['hbm_traffic_bytes'])
-    except Exception:
-        return None
+def kernel_name(dtype, parcel, moist, humidity):
+    return 'xp::k_cape_cin<%s, %d, false, %d, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
+                                                       'true' if humidity == 'specific' else 'false')
 
 
-def measured_valu_busy(nlev, ny, nx, dtype):
-    """Fraction of SIMD cycles spent issuing VALU instructions, from the same committed PMC pass
-    (SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)): the kernel is fp64-VALU-bound, so this, not the
-    HBM fraction, says how close it runs to the machine.  None for any other shape."""
-    import glob
-    if (nlev, ny, nx, dtype) != (NLEV, NY, NX, 'f64'):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
-    try:
-        d = json.load(open(files[-1]))['per_launch_mean']
-        return float(d['SQ_ACTIVE_INST_VALU'] * 4.0 / (d['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0))
-    except Exception:
-        return None
+def profile_counters(kernel, shape):
+    """HBM traffic / VALU-busy of `kernel` from a rocprofv3 PMC pass committed under profiles/ (bench.py cannot run the
+    profiler on itself) -- quoted ONLY when that pass was taken on these very kernel sources (csrc fingerprint) and on
+    this shape; otherwise the fields stay null and `source.stale` says why.  FETCH_SIZE / WRITE_SIZE are corrected as
+    MI355X_MICROARCH.md prescribes (the JSON's note)."""
+    from xarray_parcel_amd import _lib
+    sha = _lib.csrc_sha()
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get('kernel') == kernel and d.get('shape') == list(shape):
+            best = (f, d)
+    if best is None:
+        return None, None, {'file': None, 'csrc_sha': sha, 'stale': True, 'why': 'no committed PMC pass for this kernel / shape'}
+    f, d = best
+    src = {'file': os.path.relpath(f, ROOT), 'csrc_sha': d.get('csrc_sha'), 'current_csrc_sha': sha, 'stale': d.get('csrc_sha') != sha}
+    if src['stale']:
+        src['why'] = 'kernel sources changed since the PMC pass'
+        return None, None, src
+    m = d['per_launch_mean']
+    valu_busy = float(m['SQ_ACTIVE_INST_VALU'] * 4.0 / (m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0))
+    return float(d['hbm_traffic_bytes']), valu_busy, src
 
 
-def cpu_baseline(seed, nlev, sample_cols):
+def cpu_baseline(seed, nlev, sample_cols, parcel):
     import numpy as np
     from oracle import c_oracle
     from xarray_parcel_amd import synth
     c_oracle.build()
     p, t, td = synth.columns(nlev=nlev, ncol=sample_cols, seed=seed, dtype=np.float64)
-    c_oracle.cape_cin_grid(p[:, :2048], t[:, :2048], td[:, :2048], moist='rk4')          # warm up threads
+    c_oracle.cape_cin_grid(p[:, :2048], t[:, :2048], td[:, :2048], moist='rk4', parcel=parcel)   # warm up threads
     times = []
     for _ in range(5):                                   # protocol of parcel_test.py:31-35: wall clock, repeats, median
         t0 = time.perf_counter()
-        c_oracle.cape_cin_grid(p, t, td, moist='rk4')
+        c_oracle.cape_cin_grid(p, t, td, moist='rk4', parcel=parcel)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     return {'value': sample_cols / dt, 'unit': 'column-profiles/s', 'cores': c_oracle.max_threads(), 'kind': 'port',
-            'sample': f'{sample_cols} columns x {nlev} levels of the same synthetic workload, oracle/c/xp_oracle.c '
-                      f'(OpenMP), median of 5 runs, {dt:.2f} s each'}
+            'sample': f'{sample_cols} columns x {nlev} levels of the same synthetic workload ({parcel} parcel), '
+                      f'oracle/c/xp_oracle.c (OpenMP), median of 5 runs, {dt:.2f} s each'}
 
 
 def main():
@@ -85,9 +102,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS))
     ap.add_argument('--cpu-sample', type=int, default=0, help='columns for the CPU baseline (0 = auto)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--no-table-leg', action='store_true', help='skip the table-mode leg of the c2 / one-GPU run')
+    ap.add_argument('--dtype', default=None, choices=['f64', 'f32'])
     ap.add_argument('--moist', default='exact', choices=['exact', 'family', 'table'],
                     help='exact = RK4 stepper (headline); family = same ODE from the adiabat-family table (xparcel.h); '
                          'table = the reference\'s lookup tables (pf.py:525-607), generated on the GPU before the timed region')
@@ -95,10 +114,16 @@ def main():
                     help="'specific': feed specific humidity and convert on load (XP_HUM_SPECIFIC); not the headline")
     ap.add_argument('--data', default='hashed', choices=['hashed', 'smooth'],
                     help="'smooth': spatially correlated columns (sensitivity run; the headline uses SURVEY 8d's hashed columns)")
-    ap.add_argument('--nlev', type=int, default=NLEV)
-    ap.add_argument('--ny', type=int, default=NY)
-    ap.add_argument('--nx', type=int, default=NX)
+    ap.add_argument('--nlev', type=int, default=None)
+    ap.add_argument('--nt', type=int, default=None)
+    ap.add_argument('--ny', type=int, default=None, help='override the grid (rehearsals on reduced sizes)')
+    ap.add_argument('--nx', type=int, default=None)
     a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for k in ('nlev', 'nt', 'ny', 'nx', 'dtype'):
+        if getattr(a, k) is not None:
+            cfg[k] = getattr(a, k)
+    reduced = any(cfg[k] != CONFIGS[a.config][k] for k in ('nlev', 'nt', 'ny', 'nx', 'dtype'))
 
     # the in-tree library normally travels with the snapshot; if it is missing, local rank 0 builds it and the others wait
     from xarray_parcel_amd import _lib
@@ -114,6 +139,7 @@ def main():
     import torch.distributed as dist
     from xarray_parcel_amd import numpy_api as xa
     from xarray_parcel_amd import synth
+    from xarray_parcel_amd.distributed import slab_bounds
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -134,10 +160,19 @@ def main():
             dist.init_process_group(backend)
     cdev = dev if backend == 'nccl' else torch.device('cpu')       # where the gather buffers live
 
-    tdt = torch.float64 if a.dtype == 'f64' else torch.float32
-    ncol = a.ny * a.nx
-    p, t, td = synth.columns_torch(a.nlev, ncol, dev, seed=20250719, dtype=tdt, col_offset=rank * ncol,
-                                   smooth=(a.data == 'smooth'), nx=a.nx)
+    tdt = torch.float64 if cfg['dtype'] == 'f64' else torch.float32
+    nlev, nx = cfg['nlev'], cfg['nx']
+    rows = cfg['nt'] * cfg['ny']                                   # the sharded axis: y, or the flattened (time, y)
+    if cfg['scaling'] == 'weak':                                   # every rank its own grid of the configured size
+        r0, r1, total_rows = rank * rows, (rank + 1) * rows, rows * world
+    else:                                                          # one fixed grid cut into `world` slabs
+        r0, r1 = slab_bounds(rows, world, rank)
+        total_rows = rows
+    ncol = (r1 - r0) * nx
+    ncol_max = (max(slab_bounds(rows, world, r)[1] - slab_bounds(rows, world, r)[0] for r in range(world)) * nx
+                if cfg['scaling'] == 'strong' else ncol)
+    p, t, td = synth.columns_torch(nlev, ncol, dev, seed=cfg['seed'], dtype=tdt, col_offset=r0 * nx,
+                                   smooth=(a.data == 'smooth'), nx=nx)
     if a.humidity == 'specific':                                   # q of air with the synthetic dewpoint (exact inversion)
         e = 6.112 * torch.exp(17.67 * (td - 273.15) / (td - 29.65))
         w = 0.6219569100577033 * e / (p - e)
@@ -147,33 +182,39 @@ def main():
         from xarray_parcel_amd import adiabat_tables
         adiabat_tables.load_moist_adiabat_lookups(cache=False)
     want = ('cape', 'cin')
+    parcels = cfg['parcels']
     side = torch.cuda.Stream(device=dev) if world > 1 else None
-    gathered = [torch.empty((world, 2, ncol), dtype=tdt, device=cdev) for _ in range(2)] if (world > 1 and rank == 0) else None
-    sendbuf = [torch.empty((2, ncol), dtype=tdt, device=dev) for _ in range(2)] if world > 1 else None
-    kernel_ms = []
+    npar = len(parcels)
+    gathered = [torch.empty((world, 2 * npar, ncol_max), dtype=tdt, device=cdev) for _ in range(2)] if (world > 1 and rank == 0) else None
+    sendbuf = [torch.zeros((2 * npar, ncol_max), dtype=tdt, device=dev) for _ in range(2)] if world > 1 else None
+    kernel_ms = {pc: [] for pc in parcels}
 
-    def step(i, timed):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = xa.cape_cin_columns(p, t, td, want=want, moist=a.moist, humidity=a.humidity)
-        e1.record()
-        if timed:
-            kernel_ms.append((e0, e1))
+    def step(i, timed, moist):
+        res = {}
+        for pc in parcels:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            res[pc] = xa.cape_cin_columns(p, t, td, parcel=pc, want=want, moist=moist, humidity=a.humidity)
+            e1.record()
+            if timed is not None:
+                timed[pc].append((e0, e1))
         if world > 1:
             b = i & 1
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                sendbuf[b][0].copy_(r['cape'])
-                sendbuf[b][1].copy_(r['cin'])
+                for j, pc in enumerate(parcels):
+                    sendbuf[b][2 * j, :ncol].copy_(res[pc]['cape'])
+                    sendbuf[b][2 * j + 1, :ncol].copy_(res[pc]['cin'])
                 src = sendbuf[b]
                 if backend != 'nccl':
                     side.synchronize()
                     src = src.cpu()
-                dist.gather(src, list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)
-            r['cape'].record_stream(side)
-            r['cin'].record_stream(side)
-        return r
+                dist.gather(src, list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)   # the ONE collective per step
+            for pc in parcels:
+                res[pc]['cape'].record_stream(side)
+                res[pc]['cin'].record_stream(side)
+        return res
 
     def fence():
         if world > 1:
@@ -184,11 +225,11 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        step(i, False)
+        step(i, None, a.moist)
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        last = step(i, True)
+        last = step(i, kernel_ms, a.moist)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -197,33 +238,69 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        kms = [e0.elapsed_time(e1) for e0, e1 in kernel_ms]
-        avg_ms = sum(kms) / len(kms)
-        item = 8 if a.dtype == 'f64' else 4
-        bytes_launch = algorithmic_bytes_per_column(a.nlev, item) * ncol
+        item = 8 if cfg['dtype'] == 'f64' else 4
+        per_parcel = {pc: sum(e0.elapsed_time(e1) for e0, e1 in v) / len(v) for pc, v in kernel_ms.items()}
+        dom = max(per_parcel, key=per_parcel.get)                  # the dominant kernel of the step
+        avg_ms = per_parcel[dom]
+        bytes_launch = algorithmic_bytes_per_column(nlev, item) * ncol
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
+        kname = kernel_name(cfg['dtype'], dom, a.moist, a.humidity)
+        traffic, valu_busy, src = profile_counters(kname, (nlev, ncol))
+        total_cols = total_rows * nx
+        parcel_txt = ' + '.join({'surface': 'surface_based_cape_cin', 'most_unstable': 'most_unstable_cape_cin',
+                                 'mixed_layer': 'mixed_layer_cape_cin'}[pc] for pc in parcels)
         out = {
-            'metric': 'column-profiles/sec for surface_based_cape_cin', 'value': world * ncol * a.steps / dt,
+            'metric': 'column-profiles/sec for surface_based_cape_cin' if parcels == ('surface',) else
+                      'column-profiles/sec for most_unstable_cape_cin + mixed_layer_cape_cin (one column-profile = both parcels)',
+            'value': total_cols * a.steps / dt,
             'unit': 'column-profiles/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': 'synthetic' if a.data == 'hashed' else 'synthetic (spatially smooth variant, not the headline data)',
-            'config': {'workload': f'c2: synthetic {a.nlev}-level x {a.ny} x {a.nx} {a.dtype} soundings per GPU, '
-                                   f'surface_based_cape_cin (CAPE/CIN only), exact moist mode ({a.moist}), inputs resident in HBM',
-                       'columns_per_gpu': ncol, 'levels': a.nlev,
-                       'multi_gpu': 'y-slab per rank + one RCCL gather of (cape, cin) per step' if world > 1 else 'single GPU'},
+            'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': cfg['scaling'], 'vs_baseline': None,
+            'dtype': cfg['dtype'], 'data': 'synthetic' if a.data == 'hashed' else 'synthetic (spatially smooth variant, not the headline data)',
+            'config': {'workload': f"{a.config}{' (REDUCED grid: rehearsal, not the configured size)' if reduced else ''}: {cfg['what']}, "
+                                   f"{nlev} levels x {cfg['nt']} x {cfg['ny']} x {nx}, {parcel_txt} (CAPE/CIN only), "
+                                   f"moist mode {a.moist}, inputs resident in HBM",
+                       'columns_total': total_cols, 'columns_this_rank': ncol, 'levels': nlev,
+                       'multi_gpu': (f"{'own grid per rank' if cfg['scaling'] == 'weak' else 'y-slab of the one grid per rank'} + one RCCL "
+                                     f"gather of (cape, cin) per step") if world > 1 else 'single GPU',
+                       'rccl_path': 'exercised in this run' if (world > 1 and backend == 'nccl') else
+                                    ('not exercised (gloo rehearsal)' if world > 1 else 'n/a (one GPU)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a.nlev, a.ny, a.nx, a.dtype),
-                         'kernel': 'xp::k_cape_cin<%s, 0, false, %d, %s>' % ('double' if a.dtype == 'f64' else 'float',
-                                                                            {'exact': 0, 'table': 1, 'family': 2}[a.moist],
-                                                                            'true' if a.humidity == 'specific' else 'false'),
-                         'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch,
-                         'valu_busy': measured_valu_busy(a.nlev, a.ny, a.nx, a.dtype)},
-            'check': {'max_cape': float(last['cape'].max()), 'min_cin': float(last['cin'].min())},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src,
+                         'kernel': kname, 'kernel_ms': avg_ms, 'algorithmic_bytes_per_launch': bytes_launch,
+                         'valu_busy': valu_busy,
+                         'kernel_ms_by_parcel': per_parcel},
+            'check': {pc: {'max_cape': float(last[pc]['cape'].max()), 'min_cin': float(last[pc]['cin'].min())} for pc in parcels},
         }
+        if a.config == 'c2' and world == 1 and a.moist != 'table' and not a.no_table_leg and a.humidity == 'dewpoint':
+            try:                                                   # the reference's shipping moist mode, same step
+                from xarray_parcel_amd import adiabat_tables
+                t1 = time.perf_counter()
+                adiabat_tables.load_moist_adiabat_lookups(cache=False)          # generated on the GPU, outside any timed region
+                t_gen = time.perf_counter() - t1
+                tk = {pc: [] for pc in parcels}
+                for i in range(2):
+                    step(i, None, 'table')
+                fence()
+                t1 = time.perf_counter()
+                for i in range(a.steps):
+                    step(i, tk, 'table')
+                fence()
+                dtt = time.perf_counter() - t1
+                tms = sum(e0.elapsed_time(e1) for e0, e1 in tk[dom]) / len(tk[dom])
+                tname = kernel_name(cfg['dtype'], dom, 'table', a.humidity)
+                ttraffic, _, tsrc = profile_counters(tname, (nlev, ncol))
+                out['table_mode'] = {'what': "same step with the reference's lookup-table moist mode (pf.py:525-607; 31 MB index + 126 MB "
+                                             "adiabat tables resident in HBM, regenerated here)",
+                                     'value': total_cols * a.steps / dtt, 'ms_per_step': dtt / a.steps * 1e3, 'kernel': tname,
+                                     'kernel_ms': tms, 'achieved': bytes_launch / (tms * 1e-3) / 1e9,
+                                     'frac': bytes_launch / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': ttraffic,
+                                     'traffic_source': tsrc, 'table_generation_s': t_gen}
+            except Exception as e:  # a report next to the headline, never a reason to lose it
+                out['table_mode'] = {'error': str(e)}
         if not a.no_cpu and world == 1:
             try:
-                sample = a.cpu_sample or (1 << 20)
-                out['cpu_baseline'] = cpu_baseline(20250719, a.nlev, sample)
+                sample = a.cpu_sample or ((1 << 20) if nlev <= 64 else (1 << 19))
+                out['cpu_baseline'] = cpu_baseline(cfg['seed'], nlev, sample, dom)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'column-profiles/s', 'cores': 0, 'kind': 'port',
                                        'sample': f'failed: {e}'}

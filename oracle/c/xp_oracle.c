@@ -288,7 +288,17 @@ static void fam_build(double *tab) {
     free(vals);
 }
 const double *xpo_family_table(void) {
-    if (!g_fam) { g_fam = (double *)malloc(sizeof(double) * FAM_SIZE); fam_build(g_fam); }
+    /* built on first use, possibly from inside an OpenMP region: publish the pointer only when the table is complete */
+    if (!__atomic_load_n(&g_fam, __ATOMIC_ACQUIRE)) {
+#pragma omp critical(xpo_fam_init)
+        {
+            if (!g_fam) {
+                double *tab = (double *)malloc(sizeof(double) * FAM_SIZE);
+                fam_build(tab);
+                __atomic_store_n(&g_fam, tab, __ATOMIC_RELEASE);
+            }
+        }
+    }
     return g_fam;
 }
 /* tests hand one table to both sides: replace the oracle's own */

@@ -45,8 +45,9 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        src = os.path.join(_HERE, 'c', 'xp_oracle.c')
+        if not os.path.exists(_LIB_PATH) or (os.path.exists(src) and os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            build()                                        # never load a library older than its source
         _lib = C.CDLL(_LIB_PATH)
         _lib.xpo_mixed_layer.restype = D
     return _lib

@@ -24,7 +24,9 @@ def test_bench_json_contract():
     assert d['dtype'] == 'f64' and d['scaling'] == 'weak' and d['vs_baseline'] is None and 'workload' in d['config']
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
-    assert r['traffic'] is None                      # PMC traffic is only quoted for the c2 shape it was measured on
+    # PMC traffic is only quoted for the shape AND the kernel sources it was measured on; otherwise null + the reason
+    assert r['traffic'] is None and r['traffic_source']['stale'] is True
+    assert 'table_mode' in d and d['table_mode'].get('kernel_ms', 0) > 0, d.get('table_mode')   # the reference's shipping mode
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert d['value'] > 1e6
@@ -43,4 +45,28 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and 'cpu_baseline' not in d
-    assert d['config']['columns_per_gpu'] == 64 * 1024
+    assert d['config']['columns_this_rank'] == 64 * 1024 and d['config']['columns_total'] == 2 * 64 * 1024
+
+
+def test_bench_fixed_grid_configs_two_ranks_rehearsal():
+    """--config c4 / c5: ONE fixed grid cut into y-slabs (strong scaling), two ranks on one GPU, uneven slabs; and the
+    one-rank run of the same reduced grid gives the same check values (the slabs reproduce the whole)."""
+    env = dict(os.environ, XPARCEL_BENCH_SINGLE_DEVICE='1', XPARCEL_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    for cfgname, extra, rows in (('c4', ['--ny', '37', '--nx', '512'], 37), ('c5', ['--nt', '3', '--ny', '11', '--nx', '256'], 33)):
+        res = {}
+        for n in (1, 2):
+            cmd = ([sys.executable] + (['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                                        '127.0.0.1', '--master-port', '29519'] if n == 2 else []) +
+                   [os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1', '--config', cfgname, '--no-cpu'] + extra)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+            assert out.returncode == 0, out.stderr[-2000:]
+            lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+            assert len(lines) == 1
+            res[n] = json.loads(lines[0])
+        d1, d2 = res[1], res[2]
+        assert d1['scaling'] == d2['scaling'] == 'strong' and d2['n_gpus'] == 2 and d1['dtype'] == 'f32'
+        assert d1['config']['columns_total'] == d2['config']['columns_total']          # the same grid, whatever N
+        assert d2['config']['columns_this_rank'] == (rows + 1) // 2 * int(extra[-1])   # rank 0 owns the larger slab
+        assert 'REDUCED' in d1['config']['workload'] and cfgname in d1['config']['workload']
+        if cfgname == 'c5':
+            assert set(d1['roofline']['kernel_ms_by_parcel']) == {'most_unstable', 'mixed_layer'}

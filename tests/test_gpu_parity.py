@@ -139,6 +139,43 @@ def test_explicit_parcel_and_ragged_shapes():
     assert got['cape'].shape == (0,)
 
 
+def test_nan_pressure_levels():
+    """A NaN PRESSURE inside a column (outside the reference's input contract, README.md:9).
+    Above the LCL the kernel follows the reference (the level is an all-NaN node).  Below the LCL the reference's
+    insert_level puts a copy of the LCL into the NaN slot (its fill-value trick, pf.py:962-966) and integrates over the
+    resulting out-of-order profile; the kernel does NOT reproduce that artefact: it treats the level as missing --
+    exactly as if its temperature and dewpoint were missing too, the reference's own treatment of a missing level (the
+    two intervals that touch it drop out of every sum) -- and raises status bit 4 (XP_ST_NAN_PRESSURE).  This test is
+    the contract."""
+    nlev, ncol = 30, 4000
+    p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=9, dtype=np.float64)
+    base = co.cape_cin_grid(p, t, td, moist='rk4')
+    first_above = np.argmax(p < base['lcl_pressure'][None, :], axis=0)         # first level above the LCL
+    q, t2, td2 = p.copy(), t.copy(), td.copy()
+    kind = np.arange(ncol) % 3
+    below = np.nonzero((kind == 0) & (first_above >= 4))[0]
+    above = np.nonzero(kind == 1)[0]
+    kb = 1 + (np.arange(below.size) % np.maximum(first_above[below] - 3, 1))   # >= 2 levels below the LCL's lower bracket
+    ka = np.minimum(first_above[above] + 1 + (np.arange(above.size) % 5), nlev - 1)
+    q[kb, below] = np.nan
+    q[ka, above] = np.nan
+    t2[kb, below] = np.nan; td2[kb, below] = np.nan                            # the "missing level" reading of the same columns
+    got = xa.cape_cin_columns(q, t, td)
+    st = np.asarray(got['status'])
+    assert np.all(st[below] & 4) and not np.any(st[above] & 4) and not np.any(st[kind == 2] & 4)
+    # above the LCL, and untouched columns: the reference's semantics
+    ref = co.cape_cin_grid(q, t, td, moist='rk4')
+    sel = kind != 0
+    _compare({k: np.asarray(v)[sel] for k, v in got.items()}, {k: v[sel] for k, v in ref.items()}, np.float64, 1e-6)
+    # below the LCL: a missing level
+    miss = co.cape_cin_grid(p, t2, td2, moist='rk4')
+    g = {k: np.asarray(v)[below] for k, v in got.items()}
+    g['status'] = g['status'] & ~4
+    _compare(g, {k: v[below] for k, v in miss.items()}, np.float64, 1e-6)
+    # ... which is not what the reference's literal insert_level gives there (CIN picks up the duplicated LCL node)
+    assert np.max(np.abs(ref['cin'][below] - miss['cin'][below])) > 1.0
+
+
 def test_device_resident_tensors_and_3d_grid():
     import torch
     p, t, td = synth.columns(nlev=32, ncol=64 * 48, seed=5, dtype=np.float64)
@@ -157,10 +194,15 @@ def test_errors_are_loud():
         xa.cape_cin_columns(p, t, td, lcl_interp='cubic')              # pf.py:878
     with pytest.raises(AssertionError):
         xa.cape_cin_columns(p, t[:-1], td)
-    with pytest.raises(L.XParcelError) as e:
-        xa.cape_cin_columns(p, t, td, moist='table') if not L.load().xp_tables_loaded() else (_ for _ in ()).throw(
-            L.XParcelError(-3, 'skip'))
-    assert e.value.code == -3                                              # 'Call load_moist_adiabat_lookups first.'
+    # 'Call load_moist_adiabat_lookups first.' (pf.py:60): checked in a fresh process, where no test has loaded tables yet
+    import subprocess, sys
+    code = ("import numpy as np\nfrom xarray_parcel_amd import numpy_api as xa, synth, _lib as L\n"
+            "p, t, td = synth.columns(nlev=8, ncol=4, seed=1)\n"
+            "try:\n    xa.cape_cin_columns(p, t, td, moist='table')\n    print('NO ERROR')\n"
+            "except L.XParcelError as e:\n    print('CODE', e.code, str(e))\n")
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                         cwd=__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+    assert 'CODE -3' in out.stdout and 'load_moist_adiabat_lookups' in out.stdout, (out.stdout, out.stderr[-500:])
 
 
 def test_full_size_properties_config2():

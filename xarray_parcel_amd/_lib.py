@@ -122,6 +122,19 @@ def build(force=False, verbose=False, jobs=None):
     return LIB_PATH
 
 
+def csrc_sha():
+    """Fingerprint of the kernel sources (csrc/ + the ABI header): profiles taken on the GPU box record it, and bench.py
+    only quotes a profile's counters next to a timing when the fingerprints match."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(SRC_DIR)) + [INCLUDE]:
+        path = f if os.path.isabs(f) else os.path.join(SRC_DIR, f)
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 _lock = threading.Lock()
 _inited_device = None

@@ -75,10 +75,11 @@ def _fields(u, nlev, xp, k_index, saturate_some):
 
 
 def columns(nlev, ncol, seed=20250718, nan_fraction=0.0, dtype=np.float64, col_offset=0,
-            saturate_some=None):
+            saturate_some=None, nan_pressure_fraction=0.0):
     """NumPy soundings (nlev, ncol).  nan_fraction > 0 switches on the correctness-run extras:
     that fraction of columns gets NaN temperature/dewpoint levels (or a NaN surface, or is
-    NaN throughout), and ~3 % of surface parcels are saturated."""
+    NaN throughout), and ~3 % of surface parcels are saturated.  nan_pressure_fraction > 0 (opt-in, outside the
+    reference's input contract) additionally blanks ONE interior pressure level in that fraction of columns."""
     u = column_uniforms(ncol, seed, col_offset)
     if saturate_some is None:
         saturate_some = nan_fraction > 0
@@ -101,6 +102,12 @@ def columns(nlev, ncol, seed=20250718, nan_fraction=0.0, dtype=np.float64, col_o
         td[0, sfc] = np.nan
         t[:, allnan] = np.nan
         td[:, allnan] = np.nan
+    if nan_pressure_fraction > 0:
+        hit = column_uniforms(ncol, seed + 77, col_offset)
+        cols = np.nonzero(hit[0] < nan_pressure_fraction)[0]
+        levs = 1 + (hit[1][cols] * max(nlev - 2, 1)).astype(np.int64)          # never the surface level
+        p = p.copy()
+        p[np.minimum(levs, nlev - 1), cols] = np.nan
     p = np.ascontiguousarray(p.astype(dtype))
     t = np.ascontiguousarray(t.astype(dtype))
     td = np.ascontiguousarray(td.astype(dtype))
