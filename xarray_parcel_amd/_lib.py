@@ -76,12 +76,18 @@ class XParcelError(RuntimeError):
 
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC'] + os.environ.get('XP_EXTRA_DEFS', '').split()   # (A/B builds)
 # translation units: the ABI + small kernels, and k_cape_cin once per (dtype, moist mode) -- see csrc/xp_cape_tu.hip
-# The family-mode kernels (mode 2) run as ONE 768-thread workgroup per CU (3 wavefronts per SIMD): the adiabat-family
-# coefficient table (46.7 KB) is staged into LDS next to the e_s / ln tables and the per-thread scan slots (134 of the
-# CU's 160 KB).  1024 threads fit the LDS too (157.5 KB) but not the 128-VGPR budget that comes with them.
-FAMILY_THREADS = int(os.environ.get('XP_FAMILY_THREADS', '768'))
+# Per-moist-mode compile flags of the k_cape_cin translation units (XP_TU_FLAGS_<mode> overrides them for A/B builds).
+# Mode 2 (adiabat family): ONE 1024-thread workgroup per CU -- the family coefficient table (46.7 KB) is staged into LDS
+# next to the e_s / ln tables and the per-thread scan slots (157.5 of the CU's 160 KB) -- which caps the kernel at 128
+# VGPRs; -disable-machine-licm keeps the compiler from hoisting the materialisation of ~40 fp64 constants out of the
+# level loop into registers it then has to spill (128 VGPRs + 200 B of scratch with it, no spills in the loop without;
+# the RK4 kernels lose ~2 % to the flag and do not get it).
+TU_FLAGS = {0: [], 1: [], 2: ['-DXP_CAPE_THREADS=1024', '-mllvm', '-disable-machine-licm']}
+for _m in list(TU_FLAGS):
+    if os.environ.get(f'XP_TU_FLAGS_{_m}') is not None:
+        TU_FLAGS[_m] = os.environ[f'XP_TU_FLAGS_{_m}'].split()
 UNITS = [('xparcel', 'xparcel.hip', [])] + [
-    (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}'] + ([f'-DXP_CAPE_THREADS={FAMILY_THREADS}'] if m == 2 else []))
+    (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}'] + TU_FLAGS[m])
     for t in ('double', 'float') for m in (0, 1, 2)]
 
 

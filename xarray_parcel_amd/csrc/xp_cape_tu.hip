@@ -1,5 +1,6 @@
 // One translation unit of libxparcel per (XP_TU_T, XP_TU_MODE): the k_cape_cin instantiations of that data type and
-// moist mode (4 parcel modes x profile on/off x dewpoint / specific-humidity input) and the launcher that picks one.
+// moist mode (4 parcel modes x profile on/off x dewpoint / specific-humidity input, + the default-options specialisation of
+// the CAPE/CIN-only dewpoint-input kernels) and the launcher that picks one.
 // Compiled six times by the build (xarray_parcel_amd/_lib.py), e.g. -DXP_TU_T=double -DXP_TU_MODE=0.
 #include <hip/hip_runtime.h>
 
@@ -23,11 +24,12 @@ template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool pr
     const int b = cape_block();
     dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
     if (a.hum) {
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true>), gr, bl, 0, s, a);
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false>), gr, bl, 0, s, a);
     } else {
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false>), gr, bl, 0, s, a);
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false>), gr, bl, 0, s, a);
+        else if (a.vtc && a.pos_neg) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true>), gr, bl, 0, s, a);   // default options
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false>), gr, bl, 0, s, a);
     }
 }
 

@@ -44,20 +44,31 @@ XP_DEV double frcp(double x) {                       // ~1 ulp: v_rcp_f64 + two 
     return __builtin_fma(y, e, y);
 }
 XP_DEV double fdiv(double a, double b) { return a * frcp(b); }
+// a * b + c with the fp64 CONSTANT c as a scalar operand: one VALU instruction (v_fma_f64 v, v, v, s[..]) plus two s_mov on
+// the scalar pipe.  Left to itself the compiler prefers v_fmac with the constant pre-loaded into the destination by two
+// v_mov_b32 -- three VALU instructions per Horner step of a fixed-coefficient polynomial -- or, hoisting those moves out
+// of the level loop, holds every coefficient in a VGPR pair through the loop.
+XP_DEV double fma_sc(double a, double b, double c) {
+#ifdef XP_NO_FMA_SC
+    return __builtin_fma(a, b, c);
+#endif
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
 XP_DEV double fexp(double x) {                       // |rel err| < 3e-16 for |x| < 700
     double k = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);
-    double p = 2.08767569878681e-09;                 // 1/12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);
-    p = __builtin_fma(p, r, 2.755731922398589e-07);
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);
-    p = __builtin_fma(p, r, 2.48015873015873e-05);
-    p = __builtin_fma(p, r, 1.984126984126984e-04);
-    p = __builtin_fma(p, r, 1.388888888888889e-03);
-    p = __builtin_fma(p, r, 8.333333333333333e-03);
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    double p = fma_sc(2.08767569878681e-09, r, 2.505210838544172e-08);                 // 1/12! r + 1/11!
+    p = fma_sc(p, r, 2.755731922398589e-07);
+    p = fma_sc(p, r, 2.7557319223985893e-06);
+    p = fma_sc(p, r, 2.48015873015873e-05);
+    p = fma_sc(p, r, 1.984126984126984e-04);
+    p = fma_sc(p, r, 1.388888888888889e-03);
+    p = fma_sc(p, r, 8.333333333333333e-03);
+    p = fma_sc(p, r, 4.1666666666666664e-02);
+    p = fma_sc(p, r, 1.6666666666666666e-01);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -180,11 +191,10 @@ XP_DEV double log_tab(const double *tb, double x) {
     int i = (int)(m * 128.0) - 64;
     i = i < 0 ? 0 : (i > LOG_N - 1 ? LOG_N - 1 : i);
     double r = __builtin_fma(m, lt[i], -1.0);
-    double q = 1.0 / 7.0;
-    q = __builtin_fma(q, r, -1.0 / 6.0);
-    q = __builtin_fma(q, r, 0.2);
-    q = __builtin_fma(q, r, -0.25);
-    q = __builtin_fma(q, r, 1.0 / 3.0);
+    double q = fma_sc(1.0 / 7.0, r, -1.0 / 6.0);
+    q = fma_sc(q, r, 0.2);
+    q = fma_sc(q, r, -0.25);
+    q = fma_sc(q, r, 1.0 / 3.0);
     q = __builtin_fma(q, r, -0.5);
     q = __builtin_fma(q, r, 1.0);
     return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lt[ES_STRIDE + i]));
@@ -666,6 +676,11 @@ struct Scan {
             slot[SL_LFC_X * SLOT_STRIDE] = qnan(); slot[SL_LFC_T * SLOT_STRIDE] = qnan();
             slot[SL_CAPE_LFC * SLOT_STRIDE] = 0.0; slot[SL_CIN_LFC * SLOT_STRIDE] = 0.0;
         }
+        // parcel minus environment is a difference of two ROUNDED temperatures in the reference: keep the compiler from
+        // contracting the virtual-temperature product behind `par` into this subtraction (an fma would round once, and on
+        // the knife-edge nodes of a saturated parcel -- where this difference is rounding noise of exactly the
+        // reference's expressions -- that decides the sign)
+        asm volatile("" : "+v"(par), "+v"(env));
         double y = par - env;
         // same sign <=> y*yp > 0 or both zero; NaN (and the first node, yp = NaN) is "not same"
         bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);

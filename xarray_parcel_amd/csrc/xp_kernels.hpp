@@ -50,6 +50,7 @@ struct CapeArgs {
 
 enum { PM_SURFACE = 0, PM_MU = 1, PM_ML = 2, PM_EXPLICIT = 3 };
 
+
 // moisture input of one level -> dewpoint [K] (XP_HUM_SPECIFIC converts, see xparcel.h); a compile-time switch: as a
 // run-time flag it cost the dewpoint path 5 VGPRs and 3 %
 template <bool HUM> XP_DEV double as_dewpoint(const double *es, double p, double t, double m) {
@@ -147,7 +148,10 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
-template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM>
+// DEF: the reference's default option set, virtual-temperature correction on and sign-filtered sums (pf.py:1396, 1293),
+// as compile-time constants: the selects and scalar registers the run-time switches cost in the level loop go away.
+// Instantiated for the CAPE/CIN-only, dewpoint-input kernels; every other combination takes DEF = false.
+template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF>
 __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         pc = select_ml<T, HUM>(a, c, es);
     }
 
-    const bool need_w = a.vtc || PROFILE;
+    const bool vtc = DEF || (a.vtc != 0), pos_neg = DEF || (a.pos_neg != 0);
+    const bool need_w = vtc || PROFILE;
     const Lcl l = lcl(pc.p, pc.t, pc.td);
     int status = l.not_converged ? 2 : 0;
     const ScalarsOut &s = a.s;
@@ -219,8 +224,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
 
     __shared__ double s_slot[SLOT_FIELDS * SLOT_STRIDE];
-    Scan sc; sc.init(l.p, x_lcl, a.pos_neg != 0, s_slot + threadIdx.x);
-    sc.slot[SL_LCL_T * SLOT_STRIDE] = a.vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
+    Scan sc; sc.init(l.p, x_lcl, pos_neg, s_slot + threadIdx.x);
+    sc.slot[SL_LCL_T * SLOT_STRIDE] = vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
     Moist m;
     Family fam;
     if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t);
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             }
             ++jout;
         }
-        sc.node(P, X, a.vtc ? tvp : tp, a.vtc ? tve : te, is_lcl);
+        sc.node(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
     };
 
     bool lcl_done = false;
@@ -277,13 +282,23 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     // the reference's w = RH * w_s(p, T) with RH = e_s(Td) / e_s(T) (pf.py:698-704) undoes exactly the q -> Td chain --
     // so above the LCL neither the dewpoint nor the two e_s evaluations are needed (m_ then holds q, not Td)
     auto moist_node = [&](double P, double X, double T_, double m_, bool Q) __attribute__((always_inline)) {
-        // one wave-uniform range test per level instead of one per e_s evaluation
-        bool fast = __builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && (Q || in_table(m_, 0.0)))) == 0ull;
         double tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);           // NaN pressure -> NaN
-        double w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;      // pf.py:760
-        double tvp = need_w ? virt(tp, w) : tp;
-        double we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, fast);
-        double tve = need_w ? virt(T_, we) : T_;                                         // pf.py:839-843
+        // one wave-uniform range test per level instead of one per e_s evaluation; the two sides are separate code (the
+        // asm barrier keeps the compiler from merging them into one path full of selects)
+        constexpr bool PARCEL_ES = TABLE || FAMILY;                        // exact mode: e_s(T) rides along with the RK4 state
+        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tp, 0.0));
+        double ep = 0.0, we;
+        if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
+            if (need_w) ep = PARCEL_ES ? es_tab(es, tp, true) : m.e;
+            we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, true);
+        } else {
+            double tq = tp;
+            asm volatile("" : "+v"(tq));
+            if (need_w) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
+            we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, false);
+        }
+        double tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                             // pf.py:760
+        double tve = need_w ? virt(T_, we) : T_;                                          // pf.py:839-843
         emit(P, X, tp, tvp, T_, tve, m_, false);
     };
     auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
@@ -323,11 +338,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
     int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
     // software-prefetched level loop
-    double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     // Level loads: when the three views share their strides and a column's byte offset inside a level row fits 32 bits
     // (the host checks; always so for (lev, y, x) grids), one 32-bit per-lane offset serves all three arrays and the row
     // base is scalar -- instead of three 64-bit per-lane base addresses held through the loop (5 VGPRs less).
     const uint32_t voff = (uint32_t)((uint64_t)c * (uint64_t)a.p.cs * sizeof(T));
+    double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     auto load3 = [&](int64_t kk, double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
         size_t rb = (size_t)kk * (size_t)a.p.ls * sizeof(T);
         P_ = (double)*(const T *)((const char *)a.p.data + rb + voff);
@@ -335,17 +350,21 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         Td2_ = (double)*(const T *)((const char *)a.td.data + rb + voff);
     };
     if (k < a.nlev) load3(k, np_, nt_, ntd_);
+    auto next_level = [&](double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
+        P_ = np_; T2_ = nt_; M_ = ntd_;
+        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
+    };
     for (; k < a.nlev; ++k) {                                              // phase A
         if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
-        double P = np_, T_ = nt_, Td_ = as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
-        source(P, T_, Td_);
+        double P, T_, M_;
+        next_level(P, T_, M_);
+        source(P, T_, as_dewpoint<HUM>(es, P, T_, M_));
     }
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
         constexpr bool Q = HUM && !PROFILE;
-        double P = np_, T_ = nt_, m_ = Q ? ntd_ : as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
-        moist_node(P, log_tab(es, P), T_, m_, Q);
+        double P, T_, M_;
+        next_level(P, T_, M_);
+        moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (PROFILE) {
