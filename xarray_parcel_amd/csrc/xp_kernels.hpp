@@ -374,13 +374,22 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         }
     }
 
-    Scan::Result r = sc.finish(a.post_zero != 0);
+    // The output pointers are fetched from the kernel arguments only now, through a pointer the compiler cannot see
+    // through, so that it does not load all of them up front and carry ~26 scalar registers across the level loop
+    // (where they were being spilled into VGPR lanes and read back lane by lane: 840 v_readlane in the family kernel).
+    // `a` is the kernel's only parameter, so it sits at offset 0 of the kernarg segment; taking &a instead would make the
+    // compiler copy the whole struct to scratch.
+    typedef const CapeArgs __attribute__((address_space(4))) *KernargPtr;
+    KernargPtr late = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(late) : : "memory");
+    const int of64 = late->s.f64;
+    Scan::Result r = sc.finish(late->post_zero != 0);
     status |= r.status;
-    if (FAMILY) a.flags[c] = fam.bad ? 1 : 0;
-    st(s.cape, s.f64, c, r.cape); st(s.cin, s.f64, c, r.cin);
-    st(s.lfc_p, s.f64, c, r.lfc_p); st(s.lfc_t, s.f64, c, r.lfc_t);
-    st(s.el_p, s.f64, c, r.el_p); st(s.el_t, s.f64, c, r.el_t);
-    sti(s.lfc_idx, c, r.lfc_idx); sti(s.el_idx, c, r.el_idx); sti(s.status, c, status);
+    if (FAMILY) late->flags[c] = fam.bad ? 1 : 0;
+    st(late->s.cape, of64, c, r.cape); st(late->s.cin, of64, c, r.cin);
+    st(late->s.lfc_p, of64, c, r.lfc_p); st(late->s.lfc_t, of64, c, r.lfc_t);
+    st(late->s.el_p, of64, c, r.el_p); st(late->s.el_t, of64, c, r.el_t);
+    sti(late->s.lfc_idx, c, r.lfc_idx); sti(late->s.el_idx, c, r.el_idx); sti(late->s.status, c, status);
 }
 
 // parcels only (most_unstable_parcel pf.py:102, mixed_parcel pf.py:229)
