@@ -318,7 +318,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;
         }
         double tvp = need_w ? virt(tp, w) : tp;
-        double tve = need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P)) : T_;   // pf.py:839-843
+        double tve = T_;                                                   // pf.py:839-843
+        if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
+            if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
+            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
+        }
         // A level exactly ON the LCL pairs the dry temperature with the saturation mixing ratio at the moist-adiabat
         // temperature (pf.py:773 uses <=).  For a saturated parcel this is the parcel's own level and the sign of
         // parcel-minus-environment there is rounding noise of the reference's expressions, so these (rare) nodes
