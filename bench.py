@@ -16,8 +16,8 @@ side stream.  (The reference's counterpart: dask chunks over the horizontal dims
 
 Prints ONE JSON line on rank 0.  `roofline` is computed from HIP-event timings of the dominant kernel's launches inside
 the timed region; `cpu_baseline` times the CPU oracle (C restatement, OpenMP, all host cores) on a bounded sample of the
-same workload; `table_mode` (c2, one GPU) is the same step in the reference's shipping moist mode (its lookup tables,
-pf.py:525-607), measured after the headline's timed region.
+same workload; `table_mode` / `rk4_mode` (c2, one GPU) are the same step in the reference's shipping moist mode (its
+lookup tables, pf.py:525-607) and with the RK4 stepper, measured after the headline's timed region.
 """
 import argparse
 import glob
@@ -81,22 +81,23 @@ def profile_counters(kernel, shape):
     return float(d['hbm_traffic_bytes']), valu_busy, src
 
 
-def cpu_baseline(seed, nlev, sample_cols, parcel):
+def cpu_baseline(seed, nlev, sample_cols, parcel, moist):
     import numpy as np
     from oracle import c_oracle
     from xarray_parcel_amd import synth
     c_oracle.build()
     p, t, td = synth.columns(nlev=nlev, ncol=sample_cols, seed=seed, dtype=np.float64)
-    c_oracle.cape_cin_grid(p[:, :2048], t[:, :2048], td[:, :2048], moist='rk4', parcel=parcel)   # warm up threads
+    omode = 'family' if moist == 'family' else 'rk4'        # (table mode: the oracle's tables are not built here; RK4 stands in)
+    c_oracle.cape_cin_grid(p[:, :2048], t[:, :2048], td[:, :2048], moist=omode, parcel=parcel)   # warm up threads, build tables
     times = []
     for _ in range(5):                                   # protocol of parcel_test.py:31-35: wall clock, repeats, median
         t0 = time.perf_counter()
-        c_oracle.cape_cin_grid(p, t, td, moist='rk4', parcel=parcel)
+        c_oracle.cape_cin_grid(p, t, td, moist=omode, parcel=parcel)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     return {'value': sample_cols / dt, 'unit': 'column-profiles/s', 'cores': c_oracle.max_threads(), 'kind': 'port',
             'sample': f'{sample_cols} columns x {nlev} levels of the same synthetic workload ({parcel} parcel), '
-                      f'oracle/c/xp_oracle.c (OpenMP), median of 5 runs, {dt:.2f} s each'}
+                      f'oracle/c/xp_oracle.c (OpenMP, moist mode {omode}), median of 5 runs, {dt:.2f} s each'}
 
 
 def main():
@@ -109,9 +110,11 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-table-leg', action='store_true', help='skip the table-mode leg of the c2 / one-GPU run')
     ap.add_argument('--dtype', default=None, choices=['f64', 'f32'])
-    ap.add_argument('--moist', default='exact', choices=['exact', 'family', 'table'],
-                    help='exact = RK4 stepper (headline); family = same ODE from the adiabat-family table (xparcel.h); '
-                         'table = the reference\'s lookup tables (pf.py:525-607), generated on the GPU before the timed region')
+    ap.add_argument('--moist', default='family', choices=['exact', 'family', 'table'],
+                    help='family (headline) = the pseudo-adiabat ODE served from the adiabat-family table (xparcel.h: within 7.5e-7 K '
+                         'of the ODE, all 59 reference KATs pass through the C ABI in this mode); exact = the same ODE by the RK4 '
+                         'stepper (2e-5 K); table = the reference\'s lookup tables (pf.py:525-607), generated on the GPU before '
+                         'the timed region')
     ap.add_argument('--humidity', default='dewpoint', choices=['dewpoint', 'specific'],
                     help="'specific': feed specific humidity and convert on load (XP_HUM_SPECIFIC); not the headline")
     ap.add_argument('--data', default='hashed', choices=['hashed', 'smooth'],
@@ -273,36 +276,46 @@ def main():
                          'kernel_ms_by_parcel': per_parcel},
             'check': {pc: {'max_cape': float(last[pc]['cape'].max()), 'min_cin': float(last[pc]['cin'].min())} for pc in parcels},
         }
-        if a.config == 'c2' and world == 1 and a.moist != 'table' and not a.no_table_leg and a.humidity == 'dewpoint':
-            try:                                                   # the reference's shipping moist mode, same step
-                from xarray_parcel_amd import adiabat_tables
-                t1 = time.perf_counter()
-                adiabat_tables.load_moist_adiabat_lookups(cache=False)          # generated on the GPU, outside any timed region
-                t_gen = time.perf_counter() - t1
-                tk = {pc: [] for pc in parcels}
-                for i in range(2):
-                    step(i, None, 'table')
-                fence()
-                t1 = time.perf_counter()
-                for i in range(a.steps):
-                    step(i, tk, 'table')
-                fence()
-                dtt = time.perf_counter() - t1
-                tms = sum(e0.elapsed_time(e1) for e0, e1 in tk[dom]) / len(tk[dom])
-                tname = kernel_name(cfg['dtype'], dom, 'table', a.humidity)
-                ttraffic, _, tsrc = profile_counters(tname, (nlev, ncol))
-                out['table_mode'] = {'what': "same step with the reference's lookup-table moist mode (pf.py:525-607; 31 MB index + 126 MB "
-                                             "adiabat tables resident in HBM, regenerated here)",
-                                     'value': total_cols * a.steps / dtt, 'ms_per_step': dtt / a.steps * 1e3, 'kernel': tname,
-                                     'kernel_ms': tms, 'achieved': bytes_launch / (tms * 1e-3) / 1e9,
-                                     'frac': bytes_launch / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': ttraffic,
-                                     'traffic_source': tsrc, 'table_generation_s': t_gen}
-            except Exception as e:  # a report next to the headline, never a reason to lose it
-                out['table_mode'] = {'error': str(e)}
+        if a.config == 'c2' and world == 1 and not a.no_table_leg and a.humidity == 'dewpoint':
+            # the same step in the other two moist modes, measured after the headline's timed region: the reference's
+            # shipping mode (its lookup tables) and the RK4 stepper
+            legs = {'table': ('table_mode', "same step with the reference's lookup-table moist mode (pf.py:525-607; 31 MB index + 126 MB "
+                                            "adiabat tables resident in HBM, regenerated here)"),
+                    'exact': ('rk4_mode', 'same step with the RK4 stepper (XP_MOIST_EXACT)'),
+                    'family': ('family_mode', 'same step with the adiabat-family table (XP_MOIST_FAMILY)')}
+            for mode, (key, what) in legs.items():
+                if mode == a.moist:
+                    continue
+                try:
+                    t_gen = None
+                    if mode == 'table':
+                        from xarray_parcel_amd import adiabat_tables
+                        t1 = time.perf_counter()
+                        adiabat_tables.load_moist_adiabat_lookups(cache=False)      # generated on the GPU, outside any timed region
+                        t_gen = time.perf_counter() - t1
+                    tk = {pc: [] for pc in parcels}
+                    for i in range(2):
+                        step(i, None, mode)
+                    fence()
+                    t1 = time.perf_counter()
+                    for i in range(a.steps):
+                        step(i, tk, mode)
+                    fence()
+                    dtt = time.perf_counter() - t1
+                    tms = sum(e0.elapsed_time(e1) for e0, e1 in tk[dom]) / len(tk[dom])
+                    tname = kernel_name(cfg['dtype'], dom, mode, a.humidity)
+                    ttraffic, _, tsrc = profile_counters(tname, (nlev, ncol))
+                    out[key] = {'what': what, 'value': total_cols * a.steps / dtt, 'ms_per_step': dtt / a.steps * 1e3, 'kernel': tname,
+                                'kernel_ms': tms, 'achieved': bytes_launch / (tms * 1e-3) / 1e9,
+                                'frac': bytes_launch / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': ttraffic, 'traffic_source': tsrc}
+                    if t_gen is not None:
+                        out[key]['table_generation_s'] = t_gen
+                except Exception as e:  # a report next to the headline, never a reason to lose it
+                    out[key] = {'error': str(e)}
         if not a.no_cpu and world == 1:
             try:
                 sample = a.cpu_sample or ((1 << 20) if nlev <= 64 else (1 << 19))
-                out['cpu_baseline'] = cpu_baseline(cfg['seed'], nlev, sample, dom)
+                out['cpu_baseline'] = cpu_baseline(cfg['seed'], nlev, sample, dom, a.moist)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'column-profiles/s', 'cores': 0, 'kind': 'port',
                                        'sample': f'failed: {e}'}

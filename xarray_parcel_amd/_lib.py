@@ -154,6 +154,13 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise ImportError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                                   '(there is no CPU fallback)')
+            # torch ships its own HIP runtime: when torch is going to be used in this process it has to be the first to
+            # load one, or the library's hipGetDeviceCount() later reports "no ROCm-capable device" (two runtimes in one
+            # process).  torch is plumbing here (device memory, streams), so importing it is not a product dependency.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
             _lib = C.CDLL(LIB_PATH)
             _lib.xp_last_error.restype = C.c_char_p
             for s in SYMBOLS:

@@ -62,7 +62,7 @@ struct Parcel { double p, t, td; int64_t first; int idx; bool prepend; };
 // most_unstable_parcel (pf.py:102-135 with get_layer pf.py:63-100 and bound_pressure pf.py:208-227):
 // highest theta-e in the lowest `depth` hPa, first maximum wins; the layer top is the level closest to
 // p_bottom - depth (ties -> higher pressure).
-template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
+template <typename T, bool HUM> XP_DEV Parcel select_mu_exact(const CapeArgs &a, int64_t c, const double *es) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
     // one-level software prefetch: the loop is otherwise a chain of dependent HBM round trips
@@ -80,6 +80,70 @@ template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64
         if (!isnan_(e) && !(e <= best)) { best = e; r.p = p; r.t = t; r.td = td; r.first = k; r.idx = (int)k; }
         if (below) break;
     }
+    return r;
+}
+// ln(theta_e) in fp32 on the hardware's log2 / exp2 / rcp: within 1.5e-6 of the fp64 value on tropospheric soundings
+// (measured; tests/test_oracle_thermo.py), ~30 instructions instead of ~125.  Only used to rank levels.
+XP_DEV float ln_theta_e_f32(float p, float t, float td) {
+    float e = 6.112f * __builtin_amdgcn_exp2f((17.67f - 4302.645f * __builtin_amdgcn_rcpf(td - 29.65f)) * 1.4426950408889634f);
+    float r = 0.6219569100577033f * e * __builtin_amdgcn_rcpf(p - e);
+    float l2t = __builtin_amdgcn_logf(t), l2td = __builtin_amdgcn_logf(td);
+    float tl = 56.0f + __builtin_amdgcn_rcpf(__builtin_amdgcn_rcpf(td - 56.0f) + (l2t - l2td) * (0.6931471805599453f / 800.0f));
+    float l2tl = __builtin_amdgcn_logf(tl);
+    return 0.6931471805599453f * (l2t + (2.0f / 7.0f) * (9.965784284662087f - __builtin_amdgcn_logf(p - e)) + 0.28f * r * (l2t - l2tl)) +
+           r * (1.0f + 0.448f * r) * (3036.0f * __builtin_amdgcn_rcpf(tl) - 1.78f);
+}
+// The search itself: the layer's levels are ranked by the fp32 ln(theta_e); when the best level leads the runner-up by
+// more than MU_F32_WINDOW (several times the fp32 error) it is the fp64 argmax too and is taken as it stands, otherwise
+// (a near tie, ~0.1 % of columns) the column repeats the search in fp64 -- same parcel as the oracle either way.
+constexpr float MU_F32_WINDOW = 2e-5f;
+template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
+    Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
+    double bottom = qnan(), bound = qnan(), dmin = qnan();
+    float best = -__builtin_inff(), second = -__builtin_inff();
+    bool any = false, odd = false;                         // odd: a level whose fp32 value is NaN / inf while the level is usable
+    // The search has almost no arithmetic per level, so it runs at the speed of its loads: four levels are requested at a
+    // time, the next four while these are ranked (nothing else is live in registers yet at this point of the kernel).
+    constexpr int B = 4;
+    T bp[B], bt[B], bd[B], cp[B], ct[B], cd[B];
+    auto fetch = [&](int64_t k0, T *P_, T *T_, T *D_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            int64_t kk = k0 + j < a.nlev ? k0 + j : a.nlev - 1;            // clamped: rows past the top are never ranked
+            P_[j] = ((const T *)a.p.data)[kk * a.p.ls + c * a.p.cs];
+            T_[j] = ((const T *)a.t.data)[kk * a.t.ls + c * a.t.cs];
+            D_[j] = ((const T *)a.td.data)[kk * a.td.ls + c * a.td.cs];
+        }
+    };
+    fetch(0, bp, bt, bd);
+    bool done = false;
+    for (int64_t k0 = 0; k0 < a.nlev && !done; k0 += B) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) { cp[j] = bp[j]; ct[j] = bt[j]; cd[j] = bd[j]; }
+        if (k0 + B < a.nlev) fetch(k0 + B, bp, bt, bd);
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const int64_t k = k0 + j;
+            if (done || k >= a.nlev) continue;
+            double p = (double)cp[j], t = (double)ct[j], td = as_dewpoint<HUM>(es, p, t, (double)cd[j]);
+            if (isnan_(p)) continue;
+            if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
+            double d = fabs(p - bound);
+            bool below = p < bound;
+            if (below && !(d < dmin)) { done = true; continue; }
+            if (!(d >= dmin)) dmin = d;
+            if (!isnan_(t) && !isnan_(td)) {
+                float e = ln_theta_e_f32((float)p, (float)t, (float)td);
+                if (!(e > -1e30f && e < 1e30f)) odd = true;    // out of the fp32 formula's comfort zone: decide in fp64
+                if (e > best) { second = best; best = e; r.p = p; r.t = t; r.td = td; r.first = k; r.idx = (int)k; any = true; }
+                else if (e > second) second = e;
+            }
+            if (below) done = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;               // the whole wavefront has left the layer
+    }
+    bool unsure = odd || (any && !(best - second > MU_F32_WINDOW));
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull && unsure) r = select_mu_exact<T, HUM>(a, c, es);
     return r;
 }
 
@@ -340,7 +404,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
-    int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured: no gain, more registers)
+    int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured twice: no gain)
     // software-prefetched level loop
     // Level loads: when the three views share their strides and a column's byte offset inside a level row fits 32 bits
     // (the host checks; always so for (lev, y, x) grids), one 32-bit per-lane offset serves all three arrays and the row
