@@ -508,24 +508,28 @@ struct Family {
         double u = __builtin_fma(-(1.0 / FAM_WX), x_lcl, FAM_XHI * (1.0 / FAM_WX));
         int j0 = bad ? 0 : (int)u;
         j0 = j0 > FAM_NPX - 1 ? FAM_NPX - 1 : j0;
-        // Newton on the table inside piece q: T(x_lcl ; s) = sum_m b_m s^m with b_m = sum_n A[j0][n][m][q] z^n, value and
-        // derivative by one Horner sweep from m = 8 down; b_m is rebuilt from the table in every sweep instead of being
-        // kept -- nine doubles less at a point of high register pressure
+        // Newton on the table inside piece q: T(x_lcl ; s) = sum_m b_m s^m with b_m = sum_n A[j0][n][m][q] z^n (one pass
+        // over the 81 coefficients), value and derivative by one Horner sweep per step
         const double z = bad ? 0.0 : (x_lcl - x_mid(j0)) * (2.0 / FAM_WX);
         const double *a = tab + (size_t)(j0 * ((FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS) + q);
+        double b[FAM_MD + 1];
+#pragma unroll
+        for (int m = 0; m <= FAM_MD; ++m) {
+            double v = a[(FAM_ND * (FAM_MD + 1) + m) * FAM_NPS];
+#pragma unroll
+            for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[(n * (FAM_MD + 1) + m) * FAM_NPS]);
+            asm volatile("" : "+v"(v) : : "memory");
+            b[m] = v;
+        }
         double psi = psi0;
-#pragma nounroll
+#pragma unroll
         for (int it = 0; it < 3; ++it) {
             double sc = (psi - mid) * inv_h;
             double val = 0.0, der = 0.0;
 #pragma unroll
             for (int m = FAM_MD; m >= 0; --m) {
-                double v = a[(FAM_ND * (FAM_MD + 1) + m) * FAM_NPS];
-#pragma unroll
-                for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[(n * (FAM_MD + 1) + m) * FAM_NPS]);
-                asm volatile("" : "+v"(v) : : "memory");
                 der = __builtin_fma(der, sc, val);
-                val = __builtin_fma(val, sc, v);
+                val = __builtin_fma(val, sc, b[m]);
             }
             psi = psi - fdiv(val - t_lcl, der * inv_h);
         }
