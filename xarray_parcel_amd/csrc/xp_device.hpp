@@ -435,8 +435,10 @@ constexpr double FAM_LABEL_H = 0.25, FAM_MARGIN = 0.05;
 constexpr double FAM_PSI_LO = 215.0, FAM_PSI_HI = 312.0;
 #define XP_FAM_EDGES {215.0, 245.0, 262.0, 275.0, 285.0, 293.0, 299.0, 304.0, 308.5, 312.0}
 
+// device layout of the table: A[j][n][m][q] sits at ((m * 9 + n) * 8 + j) * 9 + q (see family_device_layout, xparcel.hip)
+constexpr int FAM_SM = (FAM_ND + 1) * FAM_NPX * FAM_NPS, FAM_SN = FAM_NPX * FAM_NPS, FAM_SJ = FAM_NPS;
 struct Family {
-    const double *tab;     // coefficient table [j][n][m][q], then centre[q], 1 / half-width[q]
+    const double *tab;     // coefficient table in the device layout, then centre[q], 1 / half-width[q]
     double c[FAM_ND + 1];  // the column's polynomial in z on x-piece jx
     double m4;             // z = 4 x + m4
     double s;              // the label's coordinate in psi-piece q
@@ -450,13 +452,13 @@ struct Family {
     XP_DEV static double x_mid(int j) { return FAM_XHI - FAM_WX * ((double)j + 0.5); }
     // c_n = sum_m A[j][n][m][q] s^m: nine reads in flight at a time
     XP_DEV void load_piece(int j) {
-        const double *a = tab + (size_t)(j * ((FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS) + q);
+        const double *a = tab + (j * FAM_SJ + q);
 #pragma unroll
         for (int n = 0; n <= FAM_ND; ++n) {
-            const double *r = a + n * ((FAM_MD + 1) * FAM_NPS);
-            double v = r[FAM_MD * FAM_NPS];
+            const double *r = a + n * FAM_SN;
+            double v = r[FAM_MD * FAM_SM];
 #pragma unroll
-            for (int m = FAM_MD - 1; m >= 0; --m) v = __builtin_fma(v, s, r[m * FAM_NPS]);
+            for (int m = FAM_MD - 1; m >= 0; --m) v = __builtin_fma(v, s, r[m * FAM_SM]);
             asm volatile("" : "+v"(v) : : "memory");     // this row is finished before the next row's reads are issued
             c[n] = v;
         }
@@ -511,13 +513,13 @@ struct Family {
         // Newton on the table inside piece q: T(x_lcl ; s) = sum_m b_m s^m with b_m = sum_n A[j0][n][m][q] z^n (one pass
         // over the 81 coefficients), value and derivative by one Horner sweep per step
         const double z = bad ? 0.0 : (x_lcl - x_mid(j0)) * (2.0 / FAM_WX);
-        const double *a = tab + (size_t)(j0 * ((FAM_ND + 1) * (FAM_MD + 1) * FAM_NPS) + q);
+        const double *a = tab + (j0 * FAM_SJ + q);
         double b[FAM_MD + 1];
 #pragma unroll
         for (int m = 0; m <= FAM_MD; ++m) {
-            double v = a[(FAM_ND * (FAM_MD + 1) + m) * FAM_NPS];
+            double v = a[m * FAM_SM + FAM_ND * FAM_SN];
 #pragma unroll
-            for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[(n * (FAM_MD + 1) + m) * FAM_NPS]);
+            for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[m * FAM_SM + n * FAM_SN]);
             asm volatile("" : "+v"(v) : : "memory");
             b[m] = v;
         }

@@ -174,6 +174,21 @@ void fam_append_pieces(double *tab) {
         tab[xp::FAM_COEFS + xp::FAM_NPS + q] = 1.0 / (0.5 * (kFamEdges[q + 1] - kFamEdges[q]));
     }
 }
+// The device copy is laid out [power of s][power of z][x-piece][psi-piece] (+ the appended piece constants): the nine
+// coefficients a lane multiplies through one Horner row are then 5184 B apart, beyond the reach of ds_read2_b64, so the
+// compiler issues plain ds_read_b64 (2 LDS cycles each, banks mod 64) instead of pairing them (8 cycles per pair, banks mod
+// 32) -- the same remedy as the e_s table's row stride (xp_device.hpp).  The ABI / oracle order stays [x-piece][z][s][psi].
+std::vector<double> family_device_layout(const std::vector<double> &host) {
+    const int NN = xp::FAM_ND + 1, MM = xp::FAM_MD + 1;
+    std::vector<double> dev(host.size());
+    for (int j = 0; j < xp::FAM_NPX; ++j)
+        for (int n = 0; n < NN; ++n)
+            for (int m = 0; m < MM; ++m)
+                for (int q = 0; q < xp::FAM_NPS; ++q)
+                    dev[(((size_t)m * NN + n) * xp::FAM_NPX + j) * xp::FAM_NPS + q] = host[(((size_t)j * NN + n) * MM + m) * xp::FAM_NPS + q];
+    for (int i = xp::FAM_COEFS; i < xp::FAM_SIZE; ++i) dev[i] = host[i];
+    return dev;
+}
 void build_family_table(double *tab) {
     const int NN = xp::FAM_ND + 1, MM = xp::FAM_MD + 1, NXN = xp::FAM_NPX * NN, NSN = xp::FAM_NPS * MM;
     const double pi = 3.14159265358979323846;
@@ -382,7 +397,7 @@ int xp_init(int device) {
     if (!g.fam_tab) {
         if (g.fam_host.empty()) { g.fam_host.resize((size_t)xp::FAM_SIZE); build_family_table(g.fam_host.data()); }
         HIP_TRY(hipMalloc((void **)&g.fam_tab, sizeof(double) * g.fam_host.size()));
-        HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.fam_tab, family_device_layout(g.fam_host).data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
     }
     g.device = device;
     g.init = true;
@@ -433,7 +448,7 @@ int xp_set_family_table(const double *tab, int64_t n_lnp, int64_t n_label) {
     std::lock_guard<std::mutex> lk(g.mu);
     HIP_TRY(hipDeviceSynchronize());                         // kernels in flight may still read the old table
     memcpy(g.fam_host.data(), tab, sizeof(double) * xp::FAM_COEFS);
-    HIP_TRY(hipMemcpy(g.fam_tab, g.fam_host.data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.fam_tab, family_device_layout(g.fam_host).data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
     return XP_OK;
 }
 
