@@ -248,7 +248,8 @@ XP_DEV double dewpoint_from_q(double p, double t, double q) {
 XP_DEV double dewpoint_fast(double e) { double v = flog(e * (1.0 / 6.112)); return 273.15 + 243.5 * fdiv(v, 17.67 - v); }
 XP_DEV double lcl_iter(double p, double p0, double w, double t) {
     double td = dewpoint_fast(p * fdiv(w, EPS + w));
-    return p0 * fpow(fdiv(td, t), 3.5);
+    double r = fdiv(td, t);                              // (Td / T)^(1 / kappa) = r^3.5 = r^3 sqrt(r): ~15 instructions, not exp(3.5 ln r)
+    return p0 * ((r * r) * (r * __builtin_sqrt(r)));
 }
 // pf.py:684-710 + 782-804 in the reference's own operation order (RH * w_s, then Tv), library math
 XP_DEV double virt_ref(double t, double td, double p) {
