@@ -61,11 +61,14 @@ enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1, XP_MOIST_FAMILY = 2 };
    converted to dewpoint on load with the xp_dewpoint_from_specific_humidity chain (parcel_test.py:262-266), saving the
    separate pass and the (nlev, ncol) dewpoint array.  Explicit parcels (xp_parcel.dewpoint) stay dewpoints. */
 enum { XP_HUM_DEWPOINT = 0, XP_HUM_SPECIFIC = 1 };
-/* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a table of its solutions T(ln p ; theta_w) built at
-   xp_init and interpolated 6 x 6 (within 1.4e-6 K of the ODE, the RK4 stepper of XP_MOIST_EXACT within 2e-5 K); about
-   a third fewer fp64 instructions per level.  Columns whose label or levels leave the table (theta_w outside
-   216..314 K, p outside 32..1110 hPa) are transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the
-   component entry points treat it as XP_MOIST_EXACT. */
+/* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a piecewise-polynomial table of its solutions
+   T(ln p ; psi), psi = the adiabat's temperature at 1000 hPa (8 pieces of 0.5 in ln p from 1100 hPa to ~20 hPa x 9 pieces
+   in psi from 215 to 312 K, degree 8 x 8, 46.7 KB, built at xp_init; specification: oracle/family.py).  Within 7.5e-7 K
+   of the ODE (the RK4 stepper of XP_MOIST_EXACT: 2e-5 K; MetPy's LSODA: 4e-5 ... 4e-4 K), a level costs one Horner
+   evaluation instead of an RK4 step, and all of the reference's known-answer tests pass in this mode too.  Above the
+   table's top the adiabat continues dry.  Columns whose label or LCL leave the table (psi outside 215.05 ... 311.95 K,
+   p_lcl outside ~20 ... 1100 hPa) are transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the component
+   entry points treat it as XP_MOIST_EXACT. */
 enum { XP_LCL_INTERP_LINEAR = 0, XP_LCL_INTERP_LOG = 1 };
 
 /* error codes */
@@ -83,7 +86,13 @@ enum {
 enum {
     XP_ST_TOP_NAN = 1,          /* 'Top temperature is NaN' condition of pf.py:1149 */
     XP_ST_LCL_NOT_CONVERGED = 2,/* LCL fixed point hit 50 iterations (MetPy raises)  */
-    XP_ST_NAN_PRESSURE = 4      /* a NaN pressure below the LCL: reference behaviour there is not reproduced */
+    XP_ST_BAD_PRESSURE = 8,     /* a pressure <= 0, or higher than the level below it: outside the input contract (README.md:9,
+                                   pf.py:2319-2320); the column's other outputs are unspecified */
+    XP_ST_NAN_PRESSURE = 4      /* a NaN pressure below the LCL.  The level is treated as MISSING -- exactly as if its
+                                   temperature and dewpoint were NaN too: the two intervals that touch it drop out of
+                                   every sum and the LCL bracket skips it -- not as the reference's insert_level does
+                                   (pf.py:962-966 puts a copy of the LCL into the NaN slot and integrates over the
+                                   out-of-order profile).  Contract: tests/test_gpu_parity.py::test_nan_pressure_levels */
 };
 
 typedef struct {
@@ -158,9 +167,10 @@ int xp_init(int device);
 int xp_set_tables(const xp_tables *tables);
 int xp_tables_loaded(void);
 
-/* The adiabat-family table of XP_MOIST_FAMILY, [n_lnp][n_label] doubles (no reference counterpart: the reference's
-   tables are the XP_MOIST_TABLE ones).  Read it back (out may be NULL to query the shape) or replace it, e.g. with
-   the oracle's independently built copy in the parity tests. */
+/* The coefficient table of XP_MOIST_FAMILY as [n_lnp][n_label] doubles: n_lnp = 648 rows (x-piece, power of z, power of s,
+   C-order), n_label = 9 psi-pieces (no reference counterpart: the reference's tables are the XP_MOIST_TABLE ones).  Read
+   it back (out may be NULL to query the shape) or replace it, e.g. with the oracle's independently built copy in the
+   parity tests. */
 int xp_family_table(double *out, int64_t *n_lnp, int64_t *n_label);
 int xp_set_family_table(const double *table, int64_t n_lnp, int64_t n_label);
 

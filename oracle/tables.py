@@ -75,7 +75,7 @@ def paint(index, i, profile, pressure_levels, temperatures):
     index[ip[ok].astype(np.int64), np.nonzero(ok)[0]] = i
 
 
-def build_tables(verbose=False):
+def build_tables(verbose=False, adiabat_dtype=np.float32):
     pressure_levels, temperatures = grids()
     starts = np.empty(2 * len(temperatures))
     starts[0::2] = temperatures                          # offsets 0 and temp_step/2 (pf.py:479)
@@ -84,7 +84,7 @@ def build_tables(verbose=False):
     index = np.zeros((len(pressure_levels), len(temperatures)), dtype=np.uint16)
     for i in range(prof.shape[0]):                       # later adiabats overwrite earlier ones
         paint(index, i + 1, prof[i], pressure_levels, temperatures)
-    adiabats = np.ascontiguousarray(prof[:, ::-1].astype(np.float32))      # sortby('pressure') (pf.py:54)
+    adiabats = np.ascontiguousarray(prof[:, ::-1].astype(adiabat_dtype))   # sortby('pressure') (pf.py:54)
     return Tables(index=index, adiabats=adiabats)
 
 

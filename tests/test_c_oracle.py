@@ -95,3 +95,41 @@ def test_table_mode_c_vs_python(tables):
             assert got['lfc_index'][c] == prof['lfc_index'] and got['el_index'][c] == prof['el_index']
     finally:
         po.set_moist_lapse('ode')
+
+
+def test_float32_storage_of_the_adiabats_moves_cape_by_less_than_a_hundredth(tables):
+    """The reference keeps its 14 300 adiabats in float64 (pf.py:507-511); this build stores them in float32 (126 MB
+    instead of 251 MB; rounding <= 1.5e-5 K at 250 K).  Bound of the effect on the product: surface-based CAPE / CIN in
+    table mode with the float32-stored rows against the same rows kept in float64, same index table."""
+    from oracle import tables as tb
+    from xarray_parcel_amd import synth
+    ncol = 200
+    p, t, td = synth.columns(nlev=48, ncol=ncol, seed=23, dtype=np.float64)
+    # only the rows these columns select need float64 copies: solve them again (same DOP853 call as build_tables)
+    levels, temps = tb.grids()
+    starts = np.empty(2 * len(temps)); starts[0::2] = temps; starts[1::2] = temps + tb.T_STEP / 2
+    out32, out64, rows = [], [], {}
+    for c in range(ncol):
+        po.set_moist_lapse('table', tables)
+        a = po.surface_based_cape_cin(p[:, c], t[:, c], td[:, c])
+        out32.append((a[0]['cape'], a[0]['cin']))
+        lcl_p, lcl_t = a[1]['lcl_pressure'], a[1]['lcl_temperature']
+        ip = tb.nearest_index_descending(lcl_p, tables.p_max, tables.p_step, tables.n_p)
+        jt = tb.nearest_index_ascending(lcl_t, tables.t_min, tables.t_step, tables.n_t)
+        rows[c] = int(tables.index[ip, jt])
+    need = sorted({r for r in rows.values() if r > 0})
+    prof = tb.solve_adiabats(starts[np.array(need) - 1], levels)[:, ::-1]          # float64, pressure ascending
+    assert np.max(np.abs(prof.astype(np.float32).astype(np.float64) - tables.adiabats[np.array(need) - 1])) < 1e-4
+    ad64 = tables.adiabats.astype(np.float64)                                      # float32 values everywhere ...
+    ad64[np.array(need) - 1] = prof                                                # ... float64 where it matters here
+    tab64 = tb.Tables(index=tables.index, adiabats=ad64)
+    try:
+        po.set_moist_lapse('table', tab64)
+        for c in range(ncol):
+            a = po.surface_based_cape_cin(p[:, c], t[:, c], td[:, c])
+            out64.append((a[0]['cape'], a[0]['cin']))
+    finally:
+        po.set_moist_lapse('ode')
+        po._MOIST.pop('tables', None)
+    d = np.abs(np.array(out32) - np.array(out64))
+    assert len(need) > 50 and d[:, 0].max() < 1e-2 and d[:, 1].max() < 1e-2, (len(need), d.max(axis=0))

@@ -176,6 +176,22 @@ def test_nan_pressure_levels():
     assert np.max(np.abs(ref['cin'][below] - miss['cin'][below])) > 1.0
 
 
+def test_out_of_order_pressure_raises_a_status_bit():
+    """Pressure must decrease upwards and be positive (README.md:9, pf.py:2319-2320): a column that breaks the contract is
+    flagged (XP_ST_BAD_PRESSURE = 8) instead of silently producing numbers; its neighbours are untouched."""
+    p, t, td = synth.columns(nlev=30, ncol=256, seed=4, dtype=np.float64)
+    ref = xa.cape_cin_columns(p, t, td)
+    q = p.copy()
+    q[[10, 11], 5] = q[[11, 10], 5]              # two levels swapped
+    q[20, 77] = -q[20, 77]                       # a negative pressure
+    got = xa.cape_cin_columns(q, t, td)
+    st = np.asarray(got['status'])
+    assert st[5] & 8 and st[77] & 8 and not np.any(np.delete(st, [5, 77]) & 8) and not np.any(np.asarray(ref['status']) & 8)
+    keep = np.ones(256, bool); keep[[5, 77]] = False
+    for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+        assert np.array_equal(np.asarray(got[k])[keep], np.asarray(ref[k])[keep]), k
+
+
 def test_device_resident_tensors_and_3d_grid():
     import torch
     p, t, td = synth.columns(nlev=32, ncol=64 * 48, seed=5, dtype=np.float64)

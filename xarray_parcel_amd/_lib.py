@@ -16,7 +16,7 @@ PARCEL = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
 MOIST = {'exact': 0, 'table': 1, 'family': 2}
 LCL_INTERP = {'linear': 0, 'log': 1}
 HUMIDITY = {'dewpoint': 0, 'specific': 1}
-ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE = 1, 2, 4
+ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 
 # every symbol include/xparcel.h declares
 SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',

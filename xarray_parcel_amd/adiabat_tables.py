@@ -61,6 +61,7 @@ def set_tables(index, adiabats):
     index = np.ascontiguousarray(index, dtype=np.uint16)
     adiabats = np.ascontiguousarray(adiabats, dtype=np.float32)
     assert adiabats.shape[1] == index.shape[0], 'adiabats must be [n_adiabat][n_pressure]'
+    assert int(index.max()) <= adiabats.shape[0], 'index table refers to an adiabat that is not there'
     lib = L.init()
     t = L.Tables(index.shape[0], index.shape[1], adiabats.shape[0], P_MAX, P_STEP, T_MIN, T_STEP,
                  index.ctypes.data, adiabats.ctypes.data)
@@ -78,7 +79,12 @@ def moist_adiabat_tables(regenerate=False, cache=True, base_dir=None):
     path = default_cache_path(base_dir)
     if not regenerate and os.path.exists(path):
         z = np.load(path)
-        return z['index'], z['adiabats']
+        index, adiabats = z['index'], z['adiabats']
+        # a stale or foreign cache file must not reach the device: shapes of the current grid, index entries in range
+        n_p, n_t = len(np.arange(P_MAX, 2, -P_STEP)), len(np.round(np.arange(T_MIN, 316, T_STEP), 2))
+        if (index.shape == (n_p, n_t) and adiabats.ndim == 2 and adiabats.shape[1] == n_p and
+                int(index.max()) <= adiabats.shape[0]):
+            return index, adiabats
     index, adiabats = moist_adiabat_lookup()
     if cache:
         os.makedirs(os.path.dirname(path), exist_ok=True)

@@ -601,6 +601,7 @@ struct Scan {
     // and the two exponentials a column actually needs are taken once, in finish()
     bool any_inc, pos_parcel, env_any;
     bool top_le, any_valid;  // at the last node where p, parcel, environment all exist: parcel <= environment; there is one
+    bool bad_p;              // a pressure that is not positive, or higher than the node before it (outside the input contract)
 
     XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_, double *slot_) {
         p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_; slot = slot_;
@@ -609,7 +610,7 @@ struct Scan {
         for (int f = 0; f < SLOT_FIELDS; ++f)
             slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T || f == SL_LFC_X || f == SL_EL_X || f == SL_MIN_P) ? qnan() : 0.0;
         idx()[0] = -1; idx()[1] = -1;
-        any_inc = pos_parcel = env_any = top_le = any_valid = false;
+        any_inc = pos_parcel = env_any = top_le = any_valid = bad_p = false;
     }
     XP_DEV int *idx() const { return (int *)(slot + SL_IDX * SLOT_STRIDE); }     // [0] lfc index, [1] el index
     XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
@@ -695,6 +696,7 @@ struct Scan {
         add(same ? a : 0.0);
         if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special(X, par, env, y, a);
         pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
+        bad_p = bad_p || (X > Xp) || (P <= 0.0);                            // NaN compares false: a missing pressure is not "bad"
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
@@ -717,6 +719,7 @@ struct Scan {
         bool el_ok = top_le && (el_p < p_lcl);                                  // pf.py:1151-1155
         if (!el_ok) { el_p = qnan(); el_t = qnan(); el_idx = -1; }
         if (!any_valid && env_any) r.status |= 1;                               // assert of pf.py:1149
+        if (bad_p) r.status |= 8;                                               // XP_ST_BAD_PRESSURE
         bool lfc_missing = !any_inc;
         bool replace = (pos_parcel && lfc_missing) ||
                        (!lfc_missing && isnan_(lfc_p) && (el_p < p_lcl));       // pf.py:1161-1180
