@@ -48,10 +48,10 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
 
 
 def kernel_name(dtype, parcel, moist, humidity):
-    # <T, parcel mode, profile output, moist mode, specific-humidity input, default-options specialisation>
+    # <T, parcel mode, profile output, moist mode, specific-humidity input, default options, CAPE/CIN-only outputs>
     hum = humidity == 'specific'
-    return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
-                                                           'true' if hum else 'false', 'false' if hum else 'true')
+    return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
+                                                               'true' if hum else 'false', 'false' if hum else 'true', 'false' if hum else 'true')
 
 
 def profile_counters(kernel, shape):

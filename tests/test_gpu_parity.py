@@ -113,6 +113,34 @@ def test_columns_vs_oracle(parcel, mode, dtype):
     _compare(got, ref, dtype, 1e-6)
 
 
+@pytest.mark.parametrize('parcel', ['surface', 'most_unstable', 'mixed_layer'])
+@pytest.mark.parametrize('moist', ['exact', 'family'])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_cape_cin_only_kernels_vs_oracle(parcel, moist, dtype):
+    """The LEAN instantiations (default options, no LFC / EL temperatures or indices requested -- what bench.py and a
+    multi-GPU gather launch): CAPE, CIN, the LFC / EL pressures, status and parcel index against the oracle, every
+    column, NaN / saturated columns included.  Without the indices the saturated-parcel label ties cannot be told apart
+    here, so CAPE / CIN of the (few) columns the all-outputs kernel would classify as ties are compared at 1e-6 all the
+    same -- a label tie leaves the values alone -- and only a sign tie (bounded in test_columns_vs_oracle) may differ."""
+    p, t, td = synth.columns(nlev=64, ncol=12000, seed=31, nan_fraction=0.08, dtype=dtype)
+    want = ('cape', 'cin', 'lfc_pressure', 'el_pressure', 'status', 'parcel_index', 'lcl_pressure', 'parcel_pressure')
+    got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want=want)
+    full = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist)             # the all-outputs kernel, same call otherwise
+    for k in want:
+        a, b = np.asarray(got[k]), np.asarray(full[k])
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == 'f'), k              # identical to the generic kernel, bit for bit
+    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if moist == 'exact' else 'family')
+    _, excluded = _saturated_tie_columns(full, ref)
+    keep = ~excluded
+    for k in ('cape', 'cin'):
+        a, b = np.asarray(got[k], dtype=np.float64)[keep], ref[k][keep]
+        if dtype == np.float32:
+            b = b.astype(np.float32).astype(np.float64)
+        tol = 1e-6 if dtype == np.float64 else 2e-7 * np.maximum(np.abs(b), 1.0) + 1e-6
+        assert np.all(np.abs(a - b) <= tol), (k, float(np.max(np.abs(a - b))))
+    assert np.array_equal(np.asarray(got['status'])[keep], ref['status'][keep])
+
+
 def test_profile_vs_oracle():
     p, t, td = synth.columns(nlev=40, ncol=5000, seed=11, nan_fraction=0.08, dtype=np.float64)
     for parcel in ('surface', 'most_unstable', 'mixed_layer'):

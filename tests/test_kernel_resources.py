@@ -43,18 +43,18 @@ def _resources(tmp_path, mode):
     return rec
 
 
-def _pick(rec, pm, profile, mode, hum, deflt):
-    # k_cape_cin<double, PMODE, PROFILE, MODE, HUM, DEF>
-    k = [n for n in rec if re.search(r'k_cape_cinIdLi%dELb%dELi%dELb%dELb%dE' % (pm, profile, mode, hum, deflt), n)]
-    assert len(k) == 1, (pm, profile, mode, hum, deflt, list(rec))
+def _pick(rec, pm, profile, mode, hum, deflt, lean=0):
+    # k_cape_cin<double, PMODE, PROFILE, MODE, HUM, DEF, LEAN>
+    k = [n for n in rec if re.search(r'k_cape_cinIdLi%dELb%dELi%dELb%dELb%dELb%dE' % (pm, profile, mode, hum, deflt, lean), n)]
+    assert len(k) == 1, (pm, profile, mode, hum, deflt, lean, list(rec))
     return rec[k[0]]
 
 
 @needs_hipcc
 def test_surface_kernel_keeps_four_waves_per_simd(tmp_path):
     rec = _resources(tmp_path, 0)
-    for hum, deflt in ((0, 1), (0, 0), (1, 0)):
-        r = _pick(rec, 0, 0, 0, hum, deflt)
+    for hum, deflt, lean in ((0, 1, 1), (0, 1, 0), (0, 0, 0), (1, 0, 0)):
+        r = _pick(rec, 0, 0, 0, hum, deflt, lean)
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['scratch'] <= 8, r                      # 8 B/lane is the call frame of the out-of-line slow paths
         assert r['lds'] <= 160 * 1024 // 4, r
@@ -67,7 +67,7 @@ def test_surface_kernel_keeps_four_waves_per_simd(tmp_path):
 def test_family_kernels_fit_one_workgroup_per_cu(tmp_path):
     rec = _resources(tmp_path, 2)
     for pm in (0, 1, 2, 3):
-        r = _pick(rec, pm, 0, 2, 0, 1)
+        r = _pick(rec, pm, 0, 2, 0, 1, 1)                # the bench's kernels: default options, CAPE / CIN only
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['lds'] <= 160 * 1024, r
         assert r['scratch'] <= 128, r                    # what is left is spilled in phase A, not in the steady-state loop

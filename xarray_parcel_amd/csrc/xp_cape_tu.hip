@@ -24,12 +24,14 @@ template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool pr
     const int b = cape_block();
     dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
     if (a.hum) {
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false>), gr, bl, 0, s, a);
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false, false>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false, false>), gr, bl, 0, s, a);
     } else {
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false>), gr, bl, 0, s, a);
-        else if (a.vtc && a.pos_neg) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true>), gr, bl, 0, s, a);   // default options
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false>), gr, bl, 0, s, a);
+        const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false>), gr, bl, 0, s, a);
+        else if (a.vtc && a.pos_neg && lean) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true>), gr, bl, 0, s, a);
+        else if (a.vtc && a.pos_neg) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false>), gr, bl, 0, s, a);   // default options
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false>), gr, bl, 0, s, a);
     }
 }
 

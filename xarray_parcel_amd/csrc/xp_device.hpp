@@ -629,7 +629,7 @@ struct Scan {
         return ps;
     }
     // first node, or an interval whose end points differ in sign / are NaN (pf.py:1019-1022)
-    XP_DEV void special(double X, double par, double env, double y, double a_reg) {
+    template <bool LEAN> XP_DEV void special(double X, double par, double env, double y, double a_reg) {
         if (j == 0) { use_all = (env != par); return; }
         int i = j - 1;
         // Some lane of a wavefront has a crossing in most iterations when neighbouring columns are unrelated (the
@@ -667,19 +667,23 @@ struct Scan {
             if (y > 0.0 && in_sel) {                                        // increasing crossing
                 any_inc = true;
                 if (above && !(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {        // bottom LFC above the LCL (pf.py:1127-1132)
-                    slot[SL_LFC_X * SLOT_STRIDE] = xs; idx()[0] = i;
-                    slot[SL_LFC_T * SLOT_STRIDE] = ys; slot[SL_CAPE_LFC * SLOT_STRIDE] = cape; slot[SL_CIN_LFC * SLOT_STRIDE] = cin;
+                    slot[SL_LFC_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[0] = i;
+                    if (!LEAN) slot[SL_LFC_T * SLOT_STRIDE] = ys;
+                    slot[SL_CAPE_LFC * SLOT_STRIDE] = cape; slot[SL_CIN_LFC * SLOT_STRIDE] = cin;
                 }
             }
             // top EL (pf.py:1136-1138); one at or below the LCL would be discarded by finish() anyway (pf.py:1151-1155)
             if (y < 0.0 && i >= 1 && above && !(xs >= slot[SL_EL_X * SLOT_STRIDE])) {
-                slot[SL_EL_X * SLOT_STRIDE] = xs; idx()[1] = i;
-                slot[SL_EL_T * SLOT_STRIDE] = ys; slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
+                slot[SL_EL_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[1] = i;
+                if (!LEAN) slot[SL_EL_T * SLOT_STRIDE] = ys;
+                slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
             }
         }
         add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
     }
-    XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
+    // LEAN: only CAPE / CIN (and the LFC / EL pressures) are wanted -- the LFC / EL temperatures and interval indices are not
+    // recorded, and the lowest valid pressure is left to the caller (three LDS writes less per crossing, one per level)
+    template <bool LEAN = false> XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
         if (is_lcl) {                                                       // the bracket is spent: SL_A* become the LFC record
             slot[SL_LFC_X * SLOT_STRIDE] = qnan(); slot[SL_LFC_T * SLOT_STRIDE] = qnan();
             slot[SL_CAPE_LFC * SLOT_STRIDE] = 0.0; slot[SL_CIN_LFC * SLOT_STRIDE] = 0.0;
@@ -694,13 +698,13 @@ struct Scan {
         bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
         double a = fabs(X - Xp) * ((yp + y) * 0.5);                         // pf.py:186-198
         add(same ? a : 0.0);
-        if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special(X, par, env, y, a);
+        if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN>(X, par, env, y, a);
         pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
         bad_p = bad_p || (X > Xp) || (P <= 0.0);                            // NaN compares false: a missing pressure is not "bad"
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
-        if (pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                           // lowest valid pressure so far = the last one
+        if (!LEAN && pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                  // lowest valid pressure so far = the last one (LEAN: the kernel tracks the level index instead)
         top_le = valid ? (par <= env) : top_le;
         any_valid = any_valid || valid;
         if (is_lcl) { slot[SL_CAPE_LCL * SLOT_STRIDE] = cape; slot[SL_CIN_LCL * SLOT_STRIDE] = cin; }

@@ -215,7 +215,9 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // DEF: the reference's default option set, virtual-temperature correction on and sign-filtered sums (pf.py:1396, 1293),
 // as compile-time constants: the selects and scalar registers the run-time switches cost in the level loop go away.
 // Instantiated for the CAPE/CIN-only, dewpoint-input kernels; every other combination takes DEF = false.
-template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF>
+// LEAN (with DEF): the caller wants neither LFC / EL temperatures nor interval indices (the bench, the gather of a
+// multi-GPU run): they are not tracked, see Scan::node.
+template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF, bool LEAN>
 __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int jout = 0;                                                           // profile row
+    int last_k = -1, cur_k = -1;                                            // LEAN: level index of the last valid-pressure node / of the node being fed
     auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
             if (jout < a.prof.nlev_out) {
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             }
             ++jout;
         }
-        sc.node(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
+        if (LEAN) {      // the lowest valid pressure = the last valid node: remember which level it was instead of storing P
+            if (!isnan_(P)) { last_k = (is_lcl || cur_k < 0) ? -1 : cur_k; if (is_lcl || cur_k < 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = P; }
+        }
+        sc.template node<LEAN>(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
     };
 
     bool lcl_done = false;
@@ -426,15 +432,18 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
         double P, T_, M_;
         next_level(P, T_, M_);
+        cur_k = k;
         source(P, T_, as_dewpoint<HUM>(es, P, T_, M_));
     }
     for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
         constexpr bool Q = HUM && !PROFILE;
         double P, T_, M_;
         next_level(P, T_, M_);
+        cur_k = k;
         moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
+    if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
     if (PROFILE) {
         for (; jout < a.prof.nlev_out; ++jout) {
             int64_t o = jout * a.prof.ls + c * a.prof.cs;
