@@ -86,8 +86,9 @@ enum {
 enum {
     XP_ST_TOP_NAN = 1,          /* 'Top temperature is NaN' condition of pf.py:1149 */
     XP_ST_LCL_NOT_CONVERGED = 2,/* LCL fixed point hit 50 iterations (MetPy raises)  */
-    XP_ST_BAD_PRESSURE = 8,     /* a pressure <= 0, or higher than the level below it: outside the input contract (README.md:9,
-                                   pf.py:2319-2320); the column's other outputs are unspecified */
+    XP_ST_BAD_PRESSURE = 8,     /* a pressure higher than the level below it: outside the input contract (README.md:9,
+                                   pf.py:2319-2320); the column's other outputs are unspecified.  (A pressure <= 0 has no
+                                   logarithm: it is not tested for as such, but in practice trips this test too.) */
     XP_ST_NAN_PRESSURE = 4      /* a NaN pressure below the LCL.  The level is treated as MISSING -- exactly as if its
                                    temperature and dewpoint were NaN too: the two intervals that touch it drop out of
                                    every sum and the LCL bracket skips it -- not as the reference's insert_level does

@@ -601,7 +601,7 @@ struct Scan {
     // and the two exponentials a column actually needs are taken once, in finish()
     bool any_inc, pos_parcel, env_any;
     bool top_le, any_valid;  // at the last node where p, parcel, environment all exist: parcel <= environment; there is one
-    bool bad_p;              // a pressure that is not positive, or higher than the node before it (outside the input contract)
+    bool bad_p;              // a pressure higher than the node before it (outside the input contract)
 
     XP_DEV void init(double p_lcl_, double x_lcl_, bool pos_neg_, double *slot_) {
         p_lcl = p_lcl_; x_lcl = x_lcl_; pos_neg = pos_neg_; slot = slot_;
@@ -700,7 +700,7 @@ struct Scan {
         add(same ? a : 0.0);
         if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN>(X, par, env, y, a);
         pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
-        bad_p = bad_p || (X > Xp) || (P <= 0.0);                            // NaN compares false: a missing pressure is not "bad"
+        bad_p = bad_p || (X > Xp);                                          // NaN compares false: a missing pressure is not "bad"
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
