@@ -36,6 +36,10 @@ for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100)
         ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if variant == 'exact' else variant, **kw)
     n += 1
     try:
+        if mode == 0 and variant != 'specific':      # the CAPE / CIN-only (LEAN) instantiation: bit-identical to the all-outputs kernel
+            lean = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, want=('cape', 'cin', 'lfc_pressure', 'el_pressure', 'status'))
+            for k in lean:
+                assert np.array_equal(np.asarray(lean[k]), np.asarray(got[k]), equal_nan=k != 'status'), ('lean kernel differs', k)
         tp._compare(got, ref, dtype, 1e-6)
     except AssertionError as e:
         bad += 1
