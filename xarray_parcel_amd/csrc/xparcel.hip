@@ -314,7 +314,12 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     if ((rc = stage_view(st, p, &a->p)) || (rc = stage_view(st, t, &a->t)) || (rc = stage_view(st, td, &a->td))) return rc;
     a->nlev = p->nlev; a->ncol = p->ncol;
     a->depth = parcel->depth;
-    a->es_tab = g.es_tab;
+    {   // the library's tables: read under the lock that xp_init / xp_set_tables / xp_set_family_table replace them under
+        std::lock_guard<std::mutex> lk(g.mu);
+        a->es_tab = g.es_tab;
+        a->fam_tab = g.fam_tab;
+        a->tb = g.tb;
+    }
     {   // fast level addressing (xp_kernels.hpp load3): common strides, non-negative, column offsets below 4 GiB
         bool same = a->p.ls == a->t.ls && a->p.ls == a->td.ls && a->p.cs == a->t.cs && a->p.cs == a->td.cs;
         bool fits = a->p.cs >= 0 && a->p.ls >= 0 &&
@@ -335,7 +340,6 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
                 return fail(XP_E_ARG, "more than 4 GiB per level row");
         }
     }
-    a->fam_tab = g.fam_tab;
     if (parcel->mode == XP_PARCEL_EXPLICIT) {
         if (!parcel->pressure || !parcel->temperature || !parcel->dewpoint) return fail(XP_E_ARG, "explicit parcel: null arrays");
         size_t b = (size_t)p->ncol * esize(p->dtype);
@@ -357,7 +361,6 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
     }
     if (a->table_mode) {
         if (!g.tables) return fail(XP_E_NO_TABLES, "Call load_moist_adiabat_lookups first.");
-        a->tb = g.tb;
     }
     return 0;
 }
