@@ -189,8 +189,10 @@ static void moist_lapse_table(int n, const double *p, double t0, double pref, do
 }
 
 /* ---- "adiabat family" exact mode (specification: oracle/family.py) ------------------------------------------- */
-/* T(x ; psi) = sum_n sum_m A[j][n][m][q] z^n s^m on x-pieces j (width 0.5 in ln p below ln 1100) and psi-pieces q
- * (EDGES); A = monomial form of the 9 x 9 Chebyshev-node interpolant of the ODE solution; layout [j][n][m][q]. */
+/* Tv(x ; psi) = sum_n sum_m A[j][n][m][q] z^n s^m on x-pieces j (width 0.5 in ln p below ln 1100) and psi-pieces q
+ * (EDGES): the parcel's VIRTUAL temperature T (1 + 0.608 w_s(p, T)) along the pseudo-adiabat with T = psi at 1000 hPa;
+ * A = monomial form of the 9 x 9 Chebyshev-node interpolant; layout [j][n][m][q].  The parcel temperature is the T
+ * that has this virtual temperature (Newton, fam_temperature_of). */
 #define FAM_XHI 7.003065458786462 /* ln 1100 */
 #define FAM_WX 0.5
 #define FAM_NPX 8
@@ -218,6 +220,24 @@ static double fam_rk4(double x, double t, double x1, double h_max) {
         double k4 = dt_dlnp(x + h, t + h * k3);
         t = t + h / 6.0 * (k1 + 2.0 * k2 + 2.0 * k3 + k4);
         x = x + h;
+    }
+    return t;
+}
+static double fam_virtual_temperature(double p, double t) {
+    double e = es(t);
+    return t * (1.0 + VT_EPS * (EPSILON * e / (p - e)));
+}
+/* the T with fam_virtual_temperature(p, T) = tv: five Newton steps from T0 = tv / (1 + 0.608 w_s(p, tv)) */
+static double fam_temperature_of(double p, double tv) {
+    const double c = VT_EPS * EPSILON;
+    double e0 = es(tv);
+    double t = tv / (1.0 + VT_EPS * (EPSILON * e0 / (p - e0)));
+    for (int it = 0; it < 5; it++) {
+        double e = es(t);
+        double de = e * (17.67 * 243.5) / ((t - 29.65) * (t - 29.65));
+        double f = t * (1.0 + c * e / (p - e)) - tv;
+        double df = 1.0 + c * e / (p - e) + t * c * p * de / ((p - e) * (p - e));
+        t = t - f / df;
     }
     return t;
 }
@@ -267,7 +287,7 @@ static void fam_build(double *tab) {
             for (int a = 0; a < cnt; a++) {
                 int i = order[a];
                 if (xs[i] != x) { t = fam_rk4(x, t, xs[i], FAM_BUILD_H); x = xs[i]; }
-                vals[(size_t)i * NSN + c] = t;
+                vals[(size_t)i * NSN + c] = fam_virtual_temperature(exp(xs[i]), t);
             }
         }
     }
@@ -332,12 +352,13 @@ static double fam_horner(int deg, const double *c, double u) {
     return v;
 }
 /* label psi (and its piece q) of the adiabat through (x_lcl, t_lcl); NaN when outside the table */
-static double fam_label(const double *tab, double x_lcl, double t_lcl, int *q_out) {
+static double fam_label(const double *tab, double p_lcl, double x_lcl, double t_lcl, int *q_out) {
     *q_out = -1;
     if (!(isfinite(x_lcl) && isfinite(t_lcl)) || !(x_lcl >= FAM_XLO && x_lcl <= FAM_XHI)) return NAN;
     double psi0 = (x_lcl != FAM_X1000) ? fam_rk4(x_lcl, t_lcl, FAM_X1000, FAM_LABEL_H) : t_lcl;
     if (!(psi0 >= FAM_EDGES[0] + FAM_MARGIN && psi0 <= FAM_EDGES[FAM_NPS] - FAM_MARGIN)) return NAN;
     int q = fam_spiece(psi0), j = fam_xpiece(x_lcl);
+    const double tv_lcl = fam_virtual_temperature(p_lcl, t_lcl);
     double z = (x_lcl - fam_xmid(j)) * (2.0 / FAM_WX);
     double b[FAM_MD + 1], db[FAM_MD];
     for (int m = 0; m <= FAM_MD; m++) {
@@ -349,7 +370,7 @@ static double fam_label(const double *tab, double x_lcl, double t_lcl, int *q_ou
     double inv_h = 1.0 / fam_shalf(q), psi = psi0;
     for (int it = 0; it < FAM_NEWTON; it++) {
         double s = (psi - fam_smid(q)) * inv_h;
-        psi = psi - (fam_horner(FAM_MD, b, s) - t_lcl) / (fam_horner(FAM_MD - 1, db, s) * inv_h);
+        psi = psi - (fam_horner(FAM_MD, b, s) - tv_lcl) / (fam_horner(FAM_MD - 1, db, s) * inv_h);
     }
     if (!(fabs(psi - psi0) <= FAM_MARGIN)) return NAN;
     *q_out = q;
@@ -370,11 +391,11 @@ static double fam_eval(const double *tab, double x, double psi, int q) {
 static void moist_lapse_family(int n, const double *p, double t0, double pref, double *out) {
     const double *tab = xpo_family_table();
     int q = -1;
-    double psi = (pref > 0) ? fam_label(tab, log(pref), t0, &q) : NAN;
+    double psi = (pref > 0) ? fam_label(tab, pref, log(pref), t0, &q) : NAN;
     int ok = !isnan(psi);
     for (int k = 0; k < n && ok; k++) {
         if (isnan(p[k])) { out[k] = NAN; continue; }
-        out[k] = (p[k] == pref) ? t0 : fam_eval(tab, log(p[k]), psi, q);
+        out[k] = (p[k] == pref) ? t0 : fam_temperature_of(p[k], fam_eval(tab, log(p[k]), psi, q));
         if (isnan(out[k])) ok = 0;
     }
     if (!ok) moist_lapse_rk4(n, p, t0, pref, out);      /* label or a level outside the table: whole parcel by RK4 */

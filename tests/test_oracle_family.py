@@ -20,11 +20,12 @@ def test_family_is_within_1e6_K_of_the_ode():
             continue
         ps = np.sort(rng.uniform(5, p_l, 14))[::-1]
         a = fam.moist_lapse_family(ps, t_l, p_l)
-        psi, q = fam.label(fam.table(), np.log(p_l), t_l)
+        psi, q = fam.label(fam.table(), np.log(p_l), t_l, p_l)
         if np.isnan(psi):
             assert np.array_equal(a, th.moist_lapse_rk4(ps, t_l, p_l))      # label outside the table: RK4 mode
             continue
-        assert abs(fam.evaluate(fam.table(), np.log(p_l), psi, q) - t_l) < 1e-10   # the adiabat passes through the LCL
+        assert abs(fam.evaluate(fam.table(), np.log(p_l), psi, q) - t_l) < 1e-10   # the curve passes through the LCL
+        assert abs(fam.evaluate_tv(fam.table(), np.log(p_l), psi, q) - fam.virtual_temperature(p_l, t_l)) < 1e-10
         handled += 1
         b = th.moist_lapse_ode(ps, t_l, p_l, method='DOP853', atol=1e-13, rtol=1e-13)
         inside = np.log(ps) >= fam.XLO
@@ -32,6 +33,19 @@ def test_family_is_within_1e6_K_of_the_ode():
             worst = max(worst, float(np.abs(a - b)[inside].max()))
         worst_top = max(worst_top, float(np.abs(a - b).max()))
     assert handled > 100 and worst < 1e-6 and worst_top < 3e-6, (handled, worst, worst_top)
+
+
+def test_temperature_of_inverts_the_virtual_temperature():
+    """The parcel temperature is DEFINED through the tabulated virtual temperature: five Newton steps recover T to
+    1e-12 K wherever e_s <= 0.1 p (everything a label of the table can reach)."""
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for _ in range(4000):
+        p, t = rng.uniform(20, 1100), rng.uniform(150, 317)
+        if th.saturation_vapor_pressure(t) > 0.10 * p:
+            continue
+        worst = max(worst, abs(float(fam.temperature_of(p, fam.virtual_temperature(p, t))) - t))
+    assert worst < 1e-12, worst
 
 
 def test_c_and_numpy_tables_and_lookups_agree():

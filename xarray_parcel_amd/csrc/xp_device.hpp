@@ -412,11 +412,14 @@ struct Moist {
 
 // ---- "adiabat family" exact mode -----------------------------------------------------------------------------
 // The one-parameter family of solutions of the pseudo-adiabat ODE, T(x ; psi) with x = ln p and psi = the adiabat's
-// temperature at 1000 hPa, stored once as a piecewise polynomial (specification: oracle/family.py; built by xp_init):
+// temperature at 1000 hPa, stored once -- as the parcel's VIRTUAL temperature along the adiabat,
+// Tv = T (1 + 0.608 w_s(p, T)) (pf.py:760-775: what the CAPE / CIN integration consumes, so that the steady-state level
+// needs no e_s of the parcel) -- in a piecewise polynomial (specification: oracle/family.py; built by xp_init):
 //     x-pieces j < 8   : [XHI - 0.5 (j + 1), XHI - 0.5 j], XHI = ln 1100        (1100 ... ~20 hPa)
 //     psi-pieces q < 9 : [EDGES[q], EDGES[q + 1]], 215 ... 312 K, narrower towards the warm end
-//     T = sum_n sum_m A[j][n][m][q] z^n s^m,  z, s in [-1, 1] the piece-local coordinates,  n, m <= 8
-// within 7.5e-7 K of the ODE (the RK4 stepper: 2e-5 K).  A column finds its label once (one coarse RK4 march from the
+//     Tv = sum_n sum_m A[j][n][m][q] z^n s^m,  z, s in [-1, 1] the piece-local coordinates,  n, m <= 8
+// within 7e-7 K of the ODE (the RK4 stepper: 2e-5 K).  The parcel temperature, where it is wanted (profile output, no
+// virtual-temperature correction), is the T that has this virtual temperature: Family::temperature_of.  A column finds its label once (one coarse RK4 march from the
 // LCL to 1000 hPa, then three Newton steps on the table inside the psi-piece the coarse label falls in), collapses the
 // psi direction of its current x-piece into nine coefficients held in registers, and from then on a level costs one
 // Horner evaluation (~14 fp64 instructions instead of ~155 for an RK4 step) -- no memory access in the level loop.
@@ -465,14 +468,33 @@ struct Family {
         }
         m4 = -(2.0 / FAM_WX) * x_mid(j);
     }
+    // the T with T (1 + 0.608 w_s(p, T)) = tv: five Newton steps from T0 = tv / (1 + 0.608 w_s(p, tv)) (1e-13 K wherever
+    // e_s <= 0.1 p; oracle/family.py temperature_of).  Only the kernels that output or integrate the plain temperature pay it.
+    XP_DEV static double temperature_of(const double *es, double p, double tv) {
+        constexpr double c = VT_EPS * EPS;
+        double e0 = es_tab(es, tv);
+        double t = fdiv(tv, 1.0 + c * fdiv(e0, p - e0));
+#pragma nounroll
+        for (int it = 0; it < 5; ++it) {
+            double e = es_tab(es, t);
+            double rt = frcp(t - 29.65), rp = frcp(p - e);
+            double de = e * (17.67 * 243.5) * (rt * rt);
+            double g = c * e * rp;
+            double f = __builtin_fma(t, g, t) - tv;
+            double df = 1.0 + g + t * c * p * de * (rp * rp);
+            t = t - fdiv(f, df);
+        }
+        return t;
+    }
     XP_DEV double horner(double z) const {
         double v = c[FAM_ND];
 #pragma unroll
         for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, c[n]);
         return v;
     }
-    // label of the adiabat through the LCL (x_lcl = ln p_lcl, t_lcl) and the coefficients of the x-piece the LCL is in
-    XP_DEV void start(const double *table, const double *es, double p_lcl, double x_lcl, double t_lcl) {
+    // label of the adiabat through the LCL (x_lcl = ln p_lcl, t_lcl; tv_lcl its virtual temperature there) and the
+    // coefficients of the x-piece the LCL is in
+    XP_DEV void start(const double *table, const double *es, double p_lcl, double x_lcl, double t_lcl, double tv_lcl) {
         tab = table; q = 0; s = 0.0; m4 = 0.0;
         bad = !(x_lcl >= FAM_XLO && x_lcl <= FAM_XHI) || isnan_(t_lcl);
         // coarse label: RK4 to ln 1000 in steps <= 0.25
@@ -534,13 +556,13 @@ struct Family {
                 der = __builtin_fma(der, sc, val);
                 val = __builtin_fma(val, sc, b[m]);
             }
-            psi = psi - fdiv(val - t_lcl, der * inv_h);
+            psi = psi - fdiv(val - tv_lcl, der * inv_h);
         }
         if (!(fabs(psi - psi0) <= FAM_MARGIN)) bad = true;
         s = bad ? 0.0 : (psi - mid) * inv_h;
         load_piece(j0);
     }
-    // temperature of the column's adiabat at ln p = X (X <= x_lcl; levels normally come with decreasing X).
+    // VIRTUAL temperature of the column's parcel at ln p = X (X <= x_lcl; levels normally come with decreasing X).
     // x-piece j holds z in (-1, 1]: the fast path only tests that (the piece index itself is recovered from m4 when a
     // lane has to move, with the oracle's floor rule).
     XP_DEV double at(double X) {

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     sc.slot[SL_LCL_T * SLOT_STRIDE] = vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
     Moist m;
     Family fam;
-    if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t);
+    if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t, l.tv);
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int jout = 0;                                                           // profile row
@@ -352,22 +352,31 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     // the reference's w = RH * w_s(p, T) with RH = e_s(Td) / e_s(T) (pf.py:698-704) undoes exactly the q -> Td chain --
     // so above the LCL neither the dewpoint nor the two e_s evaluations are needed (m_ then holds q, not Td)
     auto moist_node = [&](double P, double X, double T_, double m_, bool Q) __attribute__((always_inline)) {
-        double tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);           // NaN pressure -> NaN
+        // family mode: the table holds the parcel's VIRTUAL temperature; the plain temperature is derived from it only
+        // where somebody wants it (profile output, no virtual-temperature correction)
+        const double tf = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);     // NaN pressure -> NaN
         // one wave-uniform range test per level instead of one per e_s evaluation; the two sides are separate code (the
         // asm barrier keeps the compiler from merging them into one path full of selects)
-        constexpr bool PARCEL_ES = TABLE || FAMILY;                        // exact mode: e_s(T) rides along with the RK4 state
-        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tp, 0.0));
+        constexpr bool PARCEL_ES = TABLE;                                  // exact mode: e_s(T) rides along with the RK4 state
+        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tf, 0.0));
         double ep = 0.0, we;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
-            if (need_w) ep = PARCEL_ES ? es_tab(es, tp, true) : m.e;
+            if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
             we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, true);
         } else {
-            double tq = tp;
+            double tq = tf;
             asm volatile("" : "+v"(tq));
-            if (need_w) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
+            if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
             we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, false);
         }
-        double tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                             // pf.py:760
+        double tp, tvp;
+        if (FAMILY) {
+            tvp = tf;
+            tp = (PROFILE || !vtc) ? Family::temperature_of(es, P, tf) : tf;   // (not used when neither holds)
+        } else {
+            tp = tf;
+            tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                                // pf.py:760
+        }
         double tve = need_w ? virt(T_, we) : T_;                                          // pf.py:839-843
         emit(P, X, tp, tvp, T_, tve, m_, false);
     };
@@ -379,15 +388,17 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         if (!lcl_done && P < l.p) emit_lcl(P, X, T_, Td_);
         // lanes of one wavefront sit on both sides of their LCLs here: only the parcel temperature / mixing ratio
         // is branched, the environment and the scan node are shared
-        double tp, w;
+        double tp, tvp;
         if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
             tp = pc.t * fexp(KAPPA * (X - x0));
-            w = w_parcel;
+            tvp = need_w ? virt(tp, w_parcel) : tp;
+        } else if (FAMILY) {                                               // the table holds the virtual temperature
+            tvp = fam.at(X);
+            tp = (PROFILE || !vtc) ? Family::temperature_of(es, P, tvp) : tvp;
         } else {
-            tp = FAMILY ? fam.at(X) : m.at(P, X, a.tb);
-            w = need_w ? mix_of_e((TABLE || FAMILY) ? es_tab(es, tp) : m.e, P) : 0.0;
+            tp = m.at(P, X, a.tb);
+            tvp = need_w ? virt(tp, mix_of_e(TABLE ? es_tab(es, tp) : m.e, P)) : tp;
         }
-        double tvp = need_w ? virt(tp, w) : tp;
         double tve = T_;                                                   // pf.py:839-843
         if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
             if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));

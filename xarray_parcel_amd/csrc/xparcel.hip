@@ -120,8 +120,8 @@ struct Stager {
     }
 };
 
-// adiabat-family table (xp::Family; specification restated independently in oracle/family.py): the pseudo-adiabat
-// through every psi-node (Chebyshev points of every psi-piece) is marched from 1000 hPa through the x-nodes (Chebyshev
+// adiabat-family table (xp::Family; specification restated independently in oracle/family.py): the VIRTUAL temperature
+// T (1 + 0.608 w_s(p, T)) of the parcel along the pseudo-adiabat through every psi-node (Chebyshev points of every psi-piece) is marched from 1000 hPa through the x-nodes (Chebyshev
 // points of every x-piece, in order of distance) by classical RK4 with steps <= 1/80, and every (x-piece, psi-piece)
 // block of 9 x 9 values is turned into the monomial coefficients of its interpolant (long double elimination).
 double fam_dt_dlnp(double x, double t) {
@@ -208,7 +208,9 @@ void build_family_table(double *tab) {
             double x = xp::FAM_X1000, t = ps[c];
             for (int i : order) {
                 if (xs[i] != x) { t = fam_march(x, t, xs[i]); x = xs[i]; }
-                vals[(size_t)i * NSN + c] = t;
+                // the parcel's virtual temperature along the adiabat (pf.py:760 + 775), which is what the table holds
+                const double pr = std::exp(xs[i]), e = 6.112 * std::exp(17.67 * (t - 273.15) / (t - 29.65));
+                vals[(size_t)i * NSN + c] = t * (1.0 + xp::VT_EPS * (xp::EPS * e / (pr - e)));
             }
         }
     }
