@@ -48,10 +48,12 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
 
 
 def kernel_name(dtype, parcel, moist, humidity):
-    # <T, parcel mode, profile output, moist mode, specific-humidity input, default options, CAPE/CIN-only outputs>
+    # <T, parcel mode, profile output, moist mode, specific-humidity input, default options, CAPE/CIN-only outputs>; the
+    # dispatch rule of csrc/xp_cape_tu.hip: the specialised instantiations except for (family mode, surface parcel)
     hum = humidity == 'specific'
+    spec = not hum and not (moist == 'family' and parcel == 'surface')
     return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
-                                                               'true' if hum else 'false', 'false' if hum else 'true', 'false' if hum else 'true')
+                                                               'true' if hum else 'false', 'true' if spec else 'false', 'true' if spec else 'false')
 
 
 def profile_counters(kernel, shape):

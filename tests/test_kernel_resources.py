@@ -66,8 +66,11 @@ def test_surface_kernel_keeps_four_waves_per_simd(tmp_path):
 @needs_hipcc
 def test_family_kernels_fit_one_workgroup_per_cu(tmp_path):
     rec = _resources(tmp_path, 2)
-    for pm in (0, 1, 2, 3):
-        r = _pick(rec, pm, 0, 2, 0, 1, 1)                # the bench's kernels: default options, CAPE / CIN only
+    # what xp_cape_tu.hip dispatches for default options + CAPE / CIN only: the specialised instantiation for the
+    # most-unstable / mixed-layer parcels, the generic one for the surface / explicit parcel (whose specialised form the
+    # register allocator serves badly: not even instantiated)
+    for pm, deflt, lean in ((0, 0, 0), (1, 1, 1), (2, 1, 1), (3, 0, 0)):
+        r = _pick(rec, pm, 0, 2, 0, deflt, lean)
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['lds'] <= 160 * 1024, r
-        assert r['scratch'] <= 128, r                    # what is left is spilled in phase A, not in the steady-state loop
+        assert r['scratch'] <= 8, r                      # 8 B/lane is the call frame of the out-of-line slow paths

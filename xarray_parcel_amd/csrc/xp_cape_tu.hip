@@ -26,13 +26,20 @@ template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool pr
     if (a.hum) {
         if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false, false>), gr, bl, 0, s, a);
         else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false, false>), gr, bl, 0, s, a);
-    } else {
-        const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false>), gr, bl, 0, s, a);
-        else if (a.vtc && a.pos_neg && lean) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true>), gr, bl, 0, s, a);
-        else if (a.vtc && a.pos_neg) hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false>), gr, bl, 0, s, a);   // default options
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false>), gr, bl, 0, s, a);
+        return;
     }
+    if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false>), gr, bl, 0, s, a); return; }
+    // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations.  One exception, measured: for the
+    // surface / explicit parcel in family mode the specialised instantiation comes out of the register allocator at
+    // 128 VGPRs + 120 B of scratch where the generic one needs 114 and none, and runs 7 % slower -- those take the generic
+    // kernel.  tests/test_kernel_resources.py watches the numbers this rule rests on.
+    constexpr bool SPECIALISE = !(MODE == 2 && (PM == PM_SURFACE || PM == PM_EXPLICIT));
+    if constexpr (SPECIALISE) {
+        const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
+        if (a.vtc && a.pos_neg && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true>), gr, bl, 0, s, a); return; }
+        if (a.vtc && a.pos_neg) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false>), gr, bl, 0, s, a); return; }
+    }
+    hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false>), gr, bl, 0, s, a);
 }
 
 }  // namespace

@@ -49,6 +49,9 @@ struct CapeArgs {
 };
 
 enum { PM_SURFACE = 0, PM_MU = 1, PM_ML = 2, PM_EXPLICIT = 3 };
+#ifndef XP_PHASE_B_UNROLL
+#define XP_PHASE_B_UNROLL 1    // 2: phase B unrolled by two with two levels of input in flight (family translation units)
+#endif
 
 
 // moisture input of one level -> dewpoint [K] (XP_HUM_SPECIFIC converts, see xparcel.h); a compile-time switch: as a
@@ -446,12 +449,39 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         cur_k = k;
         source(P, T_, as_dewpoint<HUM>(es, P, T_, M_));
     }
-    for (; k < a.nlev; ++k) {                                              // phase B: steady state, moist adiabat only
+    {   // phase B: steady state, moist adiabat only
         constexpr bool Q = HUM && !PROFILE;
-        double P, T_, M_;
-        next_level(P, T_, M_);
-        cur_k = k;
-        moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+#if XP_PHASE_B_UNROLL == 2
+        // Unrolled by two with TWO levels of input in flight: buffer A (np_, nt_, ntd_) holds level k, buffer B level
+        // k + 1; each is requested again right after it has been copied out, i.e. two levels before it is used.  With
+        // the parcel's e_s gone a level is ~150 instructions, and one level of look-ahead no longer covers an HBM round
+        // trip under load (SQ_WAIT_ANY was 47 % of a wavefront's lifetime).
+        double bp_ = qnan(), bt_ = qnan(), bd_ = qnan();
+        if (k + 1 < a.nlev) load3(k + 1, bp_, bt_, bd_);
+        while (k + 1 < a.nlev) {
+            double P = np_, T_ = nt_, M_ = ntd_;
+            if (k + 2 < a.nlev) load3(k + 2, np_, nt_, ntd_);
+            cur_k = k;
+            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+            P = bp_; T_ = bt_; M_ = bd_;
+            if (k + 3 < a.nlev) load3(k + 3, bp_, bt_, bd_);
+            cur_k = k + 1;
+            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+            k += 2;
+        }
+        if (k < a.nlev) {
+            cur_k = k;
+            moist_node(np_, log_tab(es, np_), nt_, Q ? ntd_ : as_dewpoint<HUM>(es, np_, nt_, ntd_), Q);
+            ++k;
+        }
+#else
+        for (; k < a.nlev; ++k) {
+            double P, T_, M_;
+            next_level(P, T_, M_);
+            cur_k = k;
+            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+        }
+#endif
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
