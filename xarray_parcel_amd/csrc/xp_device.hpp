@@ -651,8 +651,10 @@ struct Scan {
         return ps;
     }
     // first node, or an interval whose end points differ in sign / are NaN (pf.py:1019-1022)
-    template <bool LEAN> XP_DEV void special(double X, double par, double env, double y, double a_reg) {
-        if (j == 0) { use_all = (env != par); return; }
+    // ABOVE: the caller guarantees that this node and the one before it lie strictly above the LCL (the kernel's phase B):
+    // every crossing then is "above the LCL" and none can tie with it
+    template <bool LEAN, bool ABOVE> XP_DEV void special(double X, double par, double env, double y, double a_reg) {
+        if (!ABOVE && j == 0) { use_all = (env != par); return; }
         int i = j - 1;
         // Some lane of a wavefront has a crossing in most iterations when neighbouring columns are unrelated (the
         // bench's are), so this path is not rare per wave: one fast reciprocal, no exp / ln.  Exceptions, behind
@@ -672,9 +674,9 @@ struct Scan {
         double zy = frac * d + yp;                                          // zero crossing of y (pf.py:1225-1231)
         if (isnan_(zy)) { add(a_reg); return; }                             // no valid zero: plain trapezoid (NaN -> skipped)
         double zlog = xs;                                                   // ln(exp(xs)) (pf.py:1237) = xs to 1 ulp
-        bool above = xs < x_lcl;                                            // p* < p_lcl
-        bool near_lcl = fabs(xs - x_lcl) <= 2e-9;
-        if (__builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
+        bool above = ABOVE || xs < x_lcl;                                   // p* < p_lcl
+        bool near_lcl = !ABOVE && fabs(xs - x_lcl) <= 2e-9;
+        if (!ABOVE && __builtin_amdgcn_ballot_w64(near_lcl) != 0ull && near_lcl) {
             double q = y;
             asm volatile("" : "+v"(q));
             xs = crossing_x_ref(q, yp, X, Xp);                              // the tie is decided on the reference's own rounding
@@ -685,7 +687,7 @@ struct Scan {
         add((yp * 0.5) * fabs(Xp - zlog));                                  // lower triangle (pf.py:1246-1273)
         double ys = frac * (par - parp) + parp;                             // pf.py:1050
         if (!isnan_(xs)) {
-            bool in_sel = use_all || i >= 1;
+            bool in_sel = ABOVE || use_all || i >= 1;
             if (y > 0.0 && in_sel) {                                        // increasing crossing
                 any_inc = true;
                 if (above && !(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {        // bottom LFC above the LCL (pf.py:1127-1132)
@@ -695,7 +697,7 @@ struct Scan {
                 }
             }
             // top EL (pf.py:1136-1138); one at or below the LCL would be discarded by finish() anyway (pf.py:1151-1155)
-            if (y < 0.0 && i >= 1 && above && !(xs >= slot[SL_EL_X * SLOT_STRIDE])) {
+            if (y < 0.0 && (ABOVE || i >= 1) && above && !(xs >= slot[SL_EL_X * SLOT_STRIDE])) {
                 slot[SL_EL_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[1] = i;
                 if (!LEAN) slot[SL_EL_T * SLOT_STRIDE] = ys;
                 slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
@@ -705,7 +707,7 @@ struct Scan {
     }
     // LEAN: only CAPE / CIN (and the LFC / EL pressures) are wanted -- the LFC / EL temperatures and interval indices are not
     // recorded, and the lowest valid pressure is left to the caller (three LDS writes less per crossing, one per level)
-    template <bool LEAN = false> XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
+    template <bool LEAN = false, bool ABOVE = false> XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
         if (is_lcl) {                                                       // the bracket is spent: SL_A* become the LFC record
             slot[SL_LFC_X * SLOT_STRIDE] = qnan(); slot[SL_LFC_T * SLOT_STRIDE] = qnan();
             slot[SL_CAPE_LFC * SLOT_STRIDE] = 0.0; slot[SL_CIN_LFC * SLOT_STRIDE] = 0.0;
@@ -720,8 +722,8 @@ struct Scan {
         bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
         double a = fabs(X - Xp) * ((yp + y) * 0.5);                         // pf.py:186-198
         add(same ? a : 0.0);
-        if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN>(X, par, env, y, a);
-        pos_parcel = pos_parcel || (P < p_lcl && par > env);                // pf.py:1166-1169
+        if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN, ABOVE>(X, par, env, y, a);
+        pos_parcel = pos_parcel || ((ABOVE || P < p_lcl) && par > env);     // pf.py:1166-1169 (ABOVE: a NaN pressure comes with a NaN parcel)
         bad_p = bad_p || (X > Xp);                                          // NaN compares false: a missing pressure is not "bad"
         env_any = env_any || !isnan_(env);
         bool pv = !isnan_(P);

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
 
     int jout = 0;                                                           // profile row
     int last_k = -1, cur_k = -1;                                            // LEAN: level index of the last valid-pressure node / of the node being fed
-    auto emit = [&](double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
+    // `above` (a std::integral_constant): this node and the one before it lie strictly above the LCL (phase B)
+    auto emit = [&](auto above, double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
             if (jout < a.prof.nlev_out) {
                 int64_t o = jout * a.prof.ls + c * a.prof.cs;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         if (LEAN) {      // the lowest valid pressure = the last valid node: remember which level it was instead of storing P
             if (!isnan_(P)) { last_k = (is_lcl || cur_k < 0) ? -1 : cur_k; if (is_lcl || cur_k < 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = P; }
         }
-        sc.template node<LEAN>(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
+        sc.template node<LEAN, decltype(above)::value>(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
     };
 
     bool lcl_done = false;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         // without profile output the scan only sees the temperature picked by the correction switch, which sits in
         // the SL_LCL_T slot: neither LCL temperature has to stay in registers through the loop
         const double lsel = br[SL_LCL_T * SLOT_STRIDE];
-        emit(l.p, x_lcl, PROFILE ? l.t : lsel, PROFILE ? l.tv : lsel, te, tve, tde, true);
+        emit(std::false_type{}, l.p, x_lcl, PROFILE ? l.t : lsel, PROFILE ? l.tv : lsel, te, tve, tde, true);
         lcl_done = true;
     };
     // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                                // pf.py:760
         }
         double tve = need_w ? virt(T_, we) : T_;                                          // pf.py:839-843
-        emit(P, X, tp, tvp, T_, tve, m_, false);
+        emit(std::true_type{}, P, X, tp, tvp, T_, tve, m_, false);
     };
     auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
         if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             tvp = tp * (1.0 + VT_EPS * (EPS * ea / (P - ea)));
             tve = virt_ref(T_, Td_, P);
         }
-        emit(P, X, tp, tvp, T_, tve, Td_, false);
+        emit(std::false_type{}, P, X, tp, tvp, T_, tve, Td_, false);
         if (!isnan_(P) && !lcl_done) { br[SL_BR_P * SLOT_STRIDE] = P; br[SL_BR_X * SLOT_STRIDE] = X; br[SL_BR_T * SLOT_STRIDE] = T_; br[SL_BR_TD * SLOT_STRIDE] = Td_; }
     };
 
