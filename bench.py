@@ -47,13 +47,18 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
     return 3 * nlev * itemsize + n_out * itemsize
 
 
-def kernel_name(dtype, parcel, moist, humidity):
-    # <T, parcel mode, profile output, moist mode, specific-humidity input, default options, CAPE/CIN-only outputs>; the
-    # dispatch rule of csrc/xp_cape_tu.hip: the specialised instantiations except for (family mode, surface parcel)
+PERSIST_MIN_COLS = int(os.environ.get('XP_PERSIST_MIN_COLS', 4 << 20))     # csrc/xparcel.hip: family mode, grids this large
+
+
+def kernel_name(dtype, parcel, moist, humidity, ncol):
+    # <T, parcel mode, profile output, moist mode, specific-humidity input, default options, CAPE/CIN-only outputs,
+    # persistent wavefronts>; the dispatch rule of csrc/xp_cape_tu.hip: the specialised instantiations except for (family
+    # mode, surface parcel); persistent wavefronts for family mode on large grids
     hum = humidity == 'specific'
     spec = not hum and not (moist == 'family' and parcel == 'surface')
-    return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
-                                                               'true' if hum else 'false', 'true' if spec else 'false', 'true' if spec else 'false')
+    tf = lambda b: 'true' if b else 'false'
+    return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
+                                                                   tf(hum), tf(spec), tf(spec), tf(moist == 'family' and ncol >= PERSIST_MIN_COLS))
 
 
 def profile_counters(kernel, shape):
@@ -251,7 +256,7 @@ def main():
         avg_ms = per_parcel[dom]
         bytes_launch = algorithmic_bytes_per_column(nlev, item) * ncol
         achieved = bytes_launch / (avg_ms * 1e-3) / 1e9
-        kname = kernel_name(cfg['dtype'], dom, a.moist, a.humidity)
+        kname = kernel_name(cfg['dtype'], dom, a.moist, a.humidity, ncol)
         traffic, valu_busy, src = profile_counters(kname, (nlev, ncol))
         total_cols = total_rows * nx
         parcel_txt = ' + '.join({'surface': 'surface_based_cape_cin', 'most_unstable': 'most_unstable_cape_cin',
@@ -305,7 +310,7 @@ def main():
                     fence()
                     dtt = time.perf_counter() - t1
                     tms = sum(e0.elapsed_time(e1) for e0, e1 in tk[dom]) / len(tk[dom])
-                    tname = kernel_name(cfg['dtype'], dom, mode, a.humidity)
+                    tname = kernel_name(cfg['dtype'], dom, mode, a.humidity, ncol)
                     ttraffic, _, tsrc = profile_counters(tname, (nlev, ncol))
                     out[key] = {'what': what, 'value': total_cols * a.steps / dtt, 'ms_per_step': dtt / a.steps * 1e3, 'kernel': tname,
                                 'kernel_ms': tms, 'achieved': bytes_launch / (tms * 1e-3) / 1e9,

@@ -10,6 +10,7 @@ resource usage).
   and spills them (200+ B / lane, reloaded every level: measured 1.33 ms instead of 0.93 on c2).
 An innocent edit can cost 10-30 % here; this test says so."""
 import os
+import itertools
 import re
 import shutil
 import subprocess
@@ -43,10 +44,10 @@ def _resources(tmp_path, mode):
     return rec
 
 
-def _pick(rec, pm, profile, mode, hum, deflt, lean=0):
-    # k_cape_cin<double, PMODE, PROFILE, MODE, HUM, DEF, LEAN>
-    k = [n for n in rec if re.search(r'k_cape_cinIdLi%dELb%dELi%dELb%dELb%dELb%dE' % (pm, profile, mode, hum, deflt, lean), n)]
-    assert len(k) == 1, (pm, profile, mode, hum, deflt, lean, list(rec))
+def _pick(rec, pm, profile, mode, hum, deflt, lean=0, persist=0):
+    # k_cape_cin<double, PMODE, PROFILE, MODE, HUM, DEF, LEAN, PERSIST>
+    k = [n for n in rec if re.search(r'k_cape_cinIdLi%dELb%dELi%dELb%dELb%dELb%dELb%dE' % (pm, profile, mode, hum, deflt, lean, persist), n)]
+    assert len(k) == 1, (pm, profile, mode, hum, deflt, lean, persist, list(rec))
     return rec[k[0]]
 
 
@@ -69,8 +70,9 @@ def test_family_kernels_fit_one_workgroup_per_cu(tmp_path):
     # what xp_cape_tu.hip dispatches for default options + CAPE / CIN only: the specialised instantiation for the
     # most-unstable / mixed-layer parcels, the generic one for the surface / explicit parcel (whose specialised form the
     # register allocator serves badly: not even instantiated)
-    for pm, deflt, lean in ((0, 0, 0), (1, 1, 1), (2, 1, 1), (3, 0, 0)):
-        r = _pick(rec, pm, 0, 2, 0, deflt, lean)
+    # -- each as an ordinary launch and with persistent wavefronts (grids of 4 Mi columns and more)
+    for (pm, deflt, lean), persist in itertools.product(((0, 0, 0), (1, 1, 1), (2, 1, 1), (3, 0, 0)), (0, 1)):
+        r = _pick(rec, pm, 0, 2, 0, deflt, lean, persist)
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['lds'] <= 160 * 1024, r
         assert r['scratch'] <= 8, r                      # 8 B/lane is the call frame of the out-of-line slow paths

@@ -20,15 +20,21 @@ int cape_block() {             // XP_CAPE_BLOCK: workgroup size for experiments 
     return b;
 }
 
-template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool profile, hipStream_t s) {
+template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeArgs &a, bool profile, hipStream_t s) {
     const int b = cape_block();
-    dim3 gr((unsigned)((a.ncol + b - 1) / b)), bl(b);
+    unsigned nblk = (unsigned)((a.ncol + b - 1) / b);
+    if (PERSIST) {                                     // persistent wavefronts: one workgroup's worth of waves per CU
+        static const int n_cu = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+        unsigned cap = (unsigned)(n_cu * (b >= 1024 ? 1 : 1024 / b));
+        if (nblk > cap) nblk = cap;
+    }
+    dim3 gr(nblk), bl(b);
     if (a.hum) {
-        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false, false>), gr, bl, 0, s, a);
-        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false, false>), gr, bl, 0, s, a);
+        if (profile) hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, true, false, false, PERSIST>), gr, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false, false, PERSIST>), gr, bl, 0, s, a);
         return;
     }
-    if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false>), gr, bl, 0, s, a); return; }
+    if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a); return; }
     // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations.  One exception, measured: for the
     // surface / explicit parcel in family mode the specialised instantiation comes out of the register allocator at
     // 128 VGPRs + 120 B of scratch where the generic one needs 114 and none, and runs 7 % slower -- those take the generic
@@ -36,10 +42,16 @@ template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool pr
     constexpr bool SPECIALISE = !(MODE == 2 && (PM == PM_SURFACE || PM == PM_EXPLICIT));
     if constexpr (SPECIALISE) {
         const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
-        if (a.vtc && a.pos_neg && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true>), gr, bl, 0, s, a); return; }
-        if (a.vtc && a.pos_neg) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false>), gr, bl, 0, s, a); return; }
+        if (a.vtc && a.pos_neg && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a); return; }
+        if (a.vtc && a.pos_neg) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false, PERSIST>), gr, bl, 0, s, a); return; }
     }
-    hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false>), gr, bl, 0, s, a);
+    hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a);
+}
+template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool profile, hipStream_t s) {
+    if constexpr (MODE == 2) {
+        if (a.tile_counter) { launch_p<T, PM, MODE, true>(a, profile, s); return; }
+    }
+    launch_p<T, PM, MODE, false>(a, profile, s);
 }
 
 }  // namespace

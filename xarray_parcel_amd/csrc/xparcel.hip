@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -482,8 +483,14 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
     }
     void *flags = nullptr;
     if (o && o->moist_mode == XP_MOIST_FAMILY && a.ncol > 0) {
-        HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)a.ncol, st.s));   // stream-ordered scratch: which columns need RK4
+        HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * ((size_t)a.ncol + 1), st.s));   // stream-ordered scratch: which columns need RK4
         a.flags = (int32_t *)flags;
+        // large grids run persistent wavefronts that take their tiles from a counter (k_cape_cin); XP_PERSIST_MIN_COLS: A/B
+        static const long long persist_min = [] { const char *e = getenv("XP_PERSIST_MIN_COLS"); return e ? atoll(e) : (4ll << 20); }();
+        if ((long long)a.ncol >= persist_min && a.ncol < (1ll << 36)) {
+            a.tile_counter = a.flags + a.ncol;
+            HIP_TRY(hipMemsetAsync(a.tile_counter, 0, sizeof(int32_t), st.s));
+        }
     }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
     else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
