@@ -47,7 +47,9 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
     return 3 * nlev * itemsize + n_out * itemsize
 
 
-PERSIST_MIN_COLS = int(os.environ.get('XP_PERSIST_MIN_COLS', 4 << 20))     # csrc/xparcel.hip: family mode, grids this large
+def persist_min_cols(parcel):     # csrc/xparcel.hip xp_cape_cin: family mode runs persistent wavefronts on grids this large
+    e = os.environ.get('XP_PERSIST_MIN_COLS')
+    return int(e) if e is not None else (1 << 19) if parcel in ('most_unstable', 'mixed_layer') else (4 << 20)
 
 
 def kernel_name(dtype, parcel, moist, humidity, ncol):
@@ -58,7 +60,7 @@ def kernel_name(dtype, parcel, moist, humidity, ncol):
     spec = not hum and not (moist == 'family' and parcel == 'surface')
     tf = lambda b: 'true' if b else 'false'
     return 'xp::k_cape_cin<%s, %d, false, %d, %s, %s, %s, %s>' % ('double' if dtype == 'f64' else 'float', PARCEL_ID[parcel], MOIST_ID[moist],
-                                                                   tf(hum), tf(spec), tf(spec), tf(moist == 'family' and ncol >= PERSIST_MIN_COLS))
+                                                                   tf(hum), tf(spec), tf(spec), tf(moist == 'family' and ncol >= persist_min_cols(parcel)))
 
 
 def profile_counters(kernel, shape):

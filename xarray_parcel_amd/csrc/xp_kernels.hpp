@@ -520,14 +520,22 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     };   // column
 
     if (PERSIST) {
+        // the first tile of every wavefront is its own number (4096 wavefronts asking the one counter at the same instant
+        // serialise: ~0.25 ms measured), the later ones come from the counter as the wavefronts finish at their own times
         const int ntiles = (int)((a.ncol + 63) >> 6);
-        for (;;) {
-            int tile = 0;
-            if ((threadIdx.x & 63) == 0) tile = atomicAdd(a.tile_counter, 1);
-            tile = __builtin_amdgcn_readfirstlane(tile);
-            if (tile >= ntiles) break;
+        const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+        int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        while (tile < ntiles) {
             const int64_t c = ((int64_t)tile << 6) + (threadIdx.x & 63);
             if (c < a.ncol) column(c);
+            if ((threadIdx.x & 63) == 0) tile = nwaves + atomicAdd(a.tile_counter, 1);
+            tile = __builtin_amdgcn_readfirstlane(tile);
+        }
+        // the last wavefront to leave puts the counter pair back to zero for the launch that takes this slot next (every
+        // other wavefront has made its last request before it counts itself out)
+        if ((threadIdx.x & 63) == 0 && atomicAdd(a.tile_counter + 1, 1) == nwaves - 1) {
+            atomicExch(a.tile_counter, 0);
+            atomicExch(a.tile_counter + 1, 0);
         }
     } else {
         column(c0);
