@@ -50,9 +50,6 @@ struct CapeArgs {
 };
 
 enum { PM_SURFACE = 0, PM_MU = 1, PM_ML = 2, PM_EXPLICIT = 3 };
-#ifndef XP_PHASE_B_UNROLL
-#define XP_PHASE_B_UNROLL 1    // 2: phase B unrolled by two with two levels of input in flight (family translation units)
-#endif
 
 
 // moisture input of one level -> dewpoint [K] (XP_HUM_SPECIFIC converts, see xparcel.h); a compile-time switch: as a
@@ -433,7 +430,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     };
 
     if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
-    int k = (int)pc.first;      // per lane for MU / ML parcels (a wave-uniform start was measured twice: no gain)
+    constexpr bool SEARCH = PMODE == PM_MU || PMODE == PM_ML;
+    int k = (int)pc.first;      // per lane for MU / ML parcels through phase A; phase B re-aligns the wavefront (below)
     // software-prefetched level loop
     // Level loads: when the three views share their strides and a column's byte offset inside a level row fits 32 bits
     // (the host checks; always so for (lev, y, x) grids), one 32-bit per-lane offset serves all three arrays and the row
@@ -451,6 +449,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         P_ = np_; T2_ = nt_; M_ = ntd_;
         if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
     };
+    constexpr bool Q = HUM && !PROFILE;
     for (; k < a.nlev; ++k) {                                              // phase A
         if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
         double P, T_, M_;
@@ -458,39 +457,29 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         cur_k = k;
         source(P, T_, as_dewpoint<HUM>(es, P, T_, M_));
     }
-    {   // phase B: steady state, moist adiabat only
-        constexpr bool Q = HUM && !PROFILE;
-#if XP_PHASE_B_UNROLL == 2
-        // Unrolled by two with TWO levels of input in flight: buffer A (np_, nt_, ntd_) holds level k, buffer B level
-        // k + 1; each is requested again right after it has been copied out, i.e. two levels before it is used.  With
-        // the parcel's e_s gone a level is ~150 instructions, and one level of look-ahead no longer covers an HBM round
-        // trip under load (SQ_WAIT_ANY was 47 % of a wavefront's lifetime).
-        double bp_ = qnan(), bt_ = qnan(), bd_ = qnan();
-        if (k + 1 < a.nlev) load3(k + 1, bp_, bt_, bd_);
-        while (k + 1 < a.nlev) {
+    if (SEARCH) {
+        // Phase B with a WAVE-UNIFORM level index.  The columns of a searching parcel start at their own levels, so after
+        // phase A the lanes stand on different levels and every load would touch as many level rows as there are distinct
+        // positions (the most-unstable kernel fetched 3.7 x its algorithmic bytes: 6.4 L2 requests per load instead of 2).
+        // From here the wavefront walks up from its lowest lane and a lane sits out until the walk reaches its own level;
+        // the lowest lane decides the number of iterations either way.
+        const int resume = k;
+        int ku = a.nlev;
+        for (int probe = 0; probe < a.nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
+        if (ku < a.nlev) load3(ku, np_, nt_, ntd_);
+        for (; ku < a.nlev; ++ku) {
             double P = np_, T_ = nt_, M_ = ntd_;
-            if (k + 2 < a.nlev) load3(k + 2, np_, nt_, ntd_);
-            cur_k = k;
-            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
-            P = bp_; T_ = bt_; M_ = bd_;
-            if (k + 3 < a.nlev) load3(k + 3, bp_, bt_, bd_);
-            cur_k = k + 1;
-            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
-            k += 2;
+            if (ku + 1 < a.nlev) load3(ku + 1, np_, nt_, ntd_);
+            cur_k = ku;
+            if (ku >= resume) moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
-        if (k < a.nlev) {
-            cur_k = k;
-            moist_node(np_, log_tab(es, np_), nt_, Q ? ntd_ : as_dewpoint<HUM>(es, np_, nt_, ntd_), Q);
-            ++k;
-        }
-#else
-        for (; k < a.nlev; ++k) {
+    } else {
+        for (; k < a.nlev; ++k) {                                          // phase B: steady state, moist adiabat only
             double P, T_, M_;
             next_level(P, T_, M_);
             cur_k = k;
             moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
-#endif
     }
     if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
