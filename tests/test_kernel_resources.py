@@ -26,10 +26,14 @@ needs_hipcc = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which('hip
 
 def _resources(tmp_path, mode):
     src = os.path.join(ROOT, 'xarray_parcel_amd', 'csrc', 'xp_cape_tu.hip')
-    cmd = ([HIPCC if os.path.exists(HIPCC) else 'hipcc'] + _lib.HIPCC_FLAGS + ['-c', '-DXP_TU_T=double', f'-DXP_TU_MODE={mode}'] +
-           _lib.TU_FLAGS[mode] + ['-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'tu.o'), src])
+    # device assembly instead of an object: the resource remarks come out the same, and the text shows whether the
+    # kernel itself spills (ScratchSize also counts the frames of the out-of-line slow paths it calls)
+    cmd = ([HIPCC if os.path.exists(HIPCC) else 'hipcc'] + [f for f in _lib.HIPCC_FLAGS if f != '-fPIC'] +
+           ['-S', '--cuda-device-only', '-DXP_TU_T=double', f'-DXP_TU_MODE={mode}'] +
+           _lib.TU_FLAGS[mode] + ['-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'tu.s'), src])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
+    asm = open(tmp_path / 'tu.s').read()
     rec, name = {}, None
     for ln in out.stderr.splitlines():
         m = re.search(r'Function Name: (\S+)', ln)
@@ -41,6 +45,10 @@ def _resources(tmp_path, mode):
             m = re.search(pat, ln)
             if m and name:
                 rec[name][key] = int(m.group(1))
+    for name in rec:                                     # spill instructions inside the function's own body
+        i = asm.find('\n' + name + ':')
+        body = asm[i:asm.find('.Lfunc_end', i)] if i >= 0 else ''
+        rec[name]['spills'] = len(re.findall(r'scratch_(?:load|store)|Folded (?:Spill|Reload)', body))
     return rec
 
 
@@ -67,12 +75,11 @@ def test_surface_kernel_keeps_four_waves_per_simd(tmp_path):
 @needs_hipcc
 def test_family_kernels_fit_one_workgroup_per_cu(tmp_path):
     rec = _resources(tmp_path, 2)
-    # what xp_cape_tu.hip dispatches for default options + CAPE / CIN only: the specialised instantiation for the
-    # most-unstable / mixed-layer parcels, the generic one for the surface / explicit parcel (whose specialised form the
-    # register allocator serves badly: not even instantiated)
+    # what xp_cape_tu.hip dispatches in family mode: the generic instantiation for every parcel (the default-options /
+    # CAPE-CIN-only specialisations come out of the register allocator at 128 VGPRs + 70..180 B of scratch here)
     # -- each as an ordinary launch and with persistent wavefronts (grids of 4 Mi columns and more)
-    for (pm, deflt, lean), persist in itertools.product(((0, 0, 0), (1, 1, 1), (2, 1, 1), (3, 0, 0)), (0, 1)):
+    for (pm, deflt, lean), persist in itertools.product(((0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0)), (0, 1)):
         r = _pick(rec, pm, 0, 2, 0, deflt, lean, persist)
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['lds'] <= 160 * 1024, r
-        assert r['scratch'] <= 8, r                      # 8 B/lane is the call frame of the out-of-line slow paths
+        assert r['spills'] == 0 and r['scratch'] <= 64, r    # no spill in the kernel; the scratch is the frames of the out-of-line slow paths

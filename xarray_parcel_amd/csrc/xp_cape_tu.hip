@@ -35,11 +35,12 @@ template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeAr
         return;
     }
     if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a); return; }
-    // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations.  One exception, measured: for the
-    // surface / explicit parcel in family mode the specialised instantiation comes out of the register allocator at
-    // 128 VGPRs + 120 B of scratch where the generic one needs 114 and none, and runs 7 % slower -- those take the generic
-    // kernel.  tests/test_kernel_resources.py watches the numbers this rule rests on.
-    constexpr bool SPECIALISE = !(MODE == 2 && (PM == PM_SURFACE || PM == PM_EXPLICIT));
+    // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations -- for the RK4 and lookup-table modes.  The family
+    // kernels sit at the 128-VGPR cap of their 1024-thread workgroups, and there the specialised instantiations come out
+    // of the register allocator WORSE than the generic one (measured, DESIGN.md 7: 128 VGPRs + 72..184 B of scratch
+    // against 122..128 and none; 7 % and more slower), so family mode always takes the generic kernel.
+    // tests/test_kernel_resources.py watches the numbers this rule rests on.
+    constexpr bool SPECIALISE = MODE != 2;
     if constexpr (SPECIALISE) {
         const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
         if (a.vtc && a.pos_neg && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a); return; }

@@ -219,7 +219,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // LEAN (with DEF): the caller wants neither LFC / EL temperatures nor interval indices (the bench, the gather of a
 // multi-GPU run): they are not tracked, see Scan::node.
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF, bool LEAN, bool PERSIST>
-__global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MODE == 2 || PROFILE) ? 3 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
+__global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MODE == 2 ? 3 : PROFILE ? 4 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
     // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
     // with 24 B of scratch or none, still a net gain); profile output and the family mode stay at 3 waves (168).  The
@@ -333,28 +333,15 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
     // phase A only
     double *const br = sc.slot;
     br[SL_BR_P * SLOT_STRIDE] = qnan(); br[SL_BR_X * SLOT_STRIDE] = qnan(); br[SL_BR_T * SLOT_STRIDE] = qnan(); br[SL_BR_TD * SLOT_STRIDE] = qnan();
-    auto emit_lcl = [&](double pa, double xa, double ta, double tda) __attribute__((always_inline)) {
-        // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811),
-        // then virtual temperature recomputed from the interpolated T, Td (pf.py:911-920)
+    // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811) between the last
+    // valid level at or below the LCL (the br slots) and the first level above it
+    auto lcl_environment = [&](double pa, double xa, double ta, double tda, double &te, double &tde) __attribute__((always_inline)) {
         double at = a.log_interp ? x_lcl : l.p;
         const double pb = br[SL_BR_P * SLOT_STRIDE], xb = br[SL_BR_X * SLOT_STRIDE], tb_ = br[SL_BR_T * SLOT_STRIDE], tdb = br[SL_BR_TD * SLOT_STRIDE];
         double cb = a.log_interp ? xb : pb, ca = a.log_interp ? xa : pa;
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
-        double te = interp_rule(tb_, ta2, at, cb, ca), tde = interp_rule(tdb, tda2, at, cb, ca);
-        // for a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at this node is rounding
-        // noise of exactly the reference's expressions: those columns evaluate them in its operation order
-        double tve = te;
-        if (need_w) {
-            bool tie = (l.p == pc.p);                                      // saturated parcel: LCL snapped onto the parcel level
-            tve = virt(te, mixing_ratio_tab(es, te, tde, l.p));
-            if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = te; asm volatile("" : "+v"(q)); tve = virt_ref(q, tde, l.p); }
-        }
-        // without profile output the scan only sees the temperature picked by the correction switch, which sits in
-        // the SL_LCL_T slot: neither LCL temperature has to stay in registers through the loop
-        const double lsel = br[SL_LCL_T * SLOT_STRIDE];
-        emit(std::false_type{}, l.p, x_lcl, PROFILE ? l.t : lsel, PROFILE ? l.tv : lsel, te, tve, tde, true);
-        lcl_done = true;
+        te = interp_rule(tb_, ta2, at, cb, ca); tde = interp_rule(tdb, tda2, at, cb, ca);
     };
     // parcel temperature / mixing ratio above the LCL; e_s(T) rides along with the RK4 state in exact mode
     // `Q`: with specific-humidity input and no profile output the environment's mixing ratio is q / (1 - q) itself --
@@ -389,16 +376,36 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         double tve = need_w ? virt(T_, we) : T_;                                          // pf.py:839-843
         emit(std::true_type{}, P, X, tp, tvp, T_, tve, m_, false);
     };
-    auto source = [&](double P, double T_, double Td_) __attribute__((always_inline)) {   // phase A: full logic
+    // Phase A: the wavefront's columns sit on both sides of their LCLs.  Every lane feeds exactly ONE node per iteration:
+    //   below its LCL       the level that was just loaded (dry adiabat);
+    //   crossing            the LCL node instead of that level (environment interpolated, pf.py:897-920) -- the level
+    //                       waits in (sP, sT, sM) and the lane is one level behind the loads from here on ("skewed");
+    //   above (skewed)      the level that has been waiting, while the one just loaded takes its place.
+    // So the node evaluation (environment e_s twice, the scan) runs once per iteration whatever the lanes are doing;
+    // inserting the LCL node as a second node of the same iteration made it run twice in almost every iteration of phase A
+    // (some lane of 64 crosses at nearly every level there: 13.4 against 6.2 us per level and Mi-column, measured).
+    // One iteration past the top level (`last`, nothing loaded) flushes the waiting level; a column whose LCL lies above
+    // the top level feeds its LCL node there, with no upper bracket (NaN environment).
+    double sP = qnan(), sT = qnan(), sM = qnan();
+    // specific-humidity input, mixed-layer parcel: the prepended parcel node carries a DEWPOINT; when it is the waiting
+    // level (a supersaturated mixed parcel lies above its own LCL) it must not be converted again, and it has to be fed by
+    // phase A, not by phase B's q-based shortcut
+    constexpr bool PREP = HUM && PMODE == PM_ML;
+    bool s_is_td = false;
+    auto source = [&](auto raw, double Pc, double Tc, double Mc, bool last, int kc) __attribute__((always_inline)) {
+        const bool skew = lcl_done;
+        double P = skew ? sP : Pc, T_ = skew ? sT : Tc;
+        const double M_ = skew ? sM : Mc;
+        double Td_ = (decltype(raw)::value && !(PREP && skew && s_is_td)) ? as_dewpoint<HUM>(es, P, T_, M_) : M_;
         if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
+        cur_k = skew ? kc - 1 : kc;
         double X = log_tab(es, P);
         X = (P == l.p) ? x_lcl : X;
-        if (isnan_(P) && !lcl_done) status |= 4;                           // NaN pressure below the LCL (see xparcel.h)
-        if (!lcl_done && P < l.p) emit_lcl(P, X, T_, Td_);
-        // lanes of one wavefront sit on both sides of their LCLs here: only the parcel temperature / mixing ratio
-        // is branched, the environment and the scan node are shared
+        const bool cross = !skew && (last || P < l.p);
+        if (isnan_(P) && !skew && !last) status |= 4;                      // NaN pressure below the LCL (see xparcel.h)
+        // only the parcel temperature / mixing ratio is branched, the environment and the scan node are shared
         double tp, tvp;
-        if (P >= l.p) {                                                    // dry adiabat (pf.py:313, 767)
+        if (!skew) {                                                       // dry adiabat (pf.py:313, 767)
             tp = pc.t * fexp(KAPPA * (X - x0));
             tvp = need_w ? virt(tp, w_parcel) : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
@@ -408,16 +415,27 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             tp = m.at(P, X, a.tb);
             tvp = need_w ? virt(tp, mix_of_e(TABLE ? es_tab(es, tp) : m.e, P)) : tp;
         }
-        double tve = T_;                                                   // pf.py:839-843
+        if (__builtin_amdgcn_ballot_w64(cross) != 0ull && cross) {          // this lane's node is its LCL
+            double te, tde;
+            lcl_environment(P, X, T_, Td_, te, tde);
+            // without profile output the scan only sees the temperature picked by the correction switch, which sits in
+            // the SL_LCL_T slot: neither LCL temperature has to stay in registers through the loop
+            const double lsel = br[SL_LCL_T * SLOT_STRIDE];
+            P = l.p; X = x_lcl; T_ = te; Td_ = tde;
+            tp = PROFILE ? l.t : lsel; tvp = PROFILE ? l.tv : lsel;
+        }
+        double tve = T_;                                                   // pf.py:839-843, 911-920
         if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
             if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
             else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
         }
+        // For a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at the LCL node is rounding
+        // noise of exactly the reference's expressions: those columns evaluate them in its operation order.
+        const bool tie = need_w && cross && (l.p == pc.p);
+        if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = T_; asm volatile("" : "+v"(q)); tve = virt_ref(q, Td_, l.p); }
         // A level exactly ON the LCL pairs the dry temperature with the saturation mixing ratio at the moist-adiabat
-        // temperature (pf.py:773 uses <=).  For a saturated parcel this is the parcel's own level and the sign of
-        // parcel-minus-environment there is rounding noise of the reference's expressions, so these (rare) nodes
-        // evaluate them in its operation order with library math.
-        bool on_lcl = need_w && (P == l.p);
+        // temperature (pf.py:773 uses <=).  For a saturated parcel this is the parcel's own level and the same holds.
+        const bool on_lcl = need_w && !cross && (P == l.p);
         if (__builtin_amdgcn_ballot_w64(on_lcl) != 0ull && on_lcl) {
             double ta = FAMILY ? l.t : m.at(P, X, a.tb);
             asm volatile("" : "+v"(ta));
@@ -425,11 +443,14 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
             tvp = tp * (1.0 + VT_EPS * (EPS * ea / (P - ea)));
             tve = virt_ref(T_, Td_, P);
         }
-        emit(std::false_type{}, P, X, tp, tvp, T_, tve, Td_, false);
-        if (!isnan_(P) && !lcl_done) { br[SL_BR_P * SLOT_STRIDE] = P; br[SL_BR_X * SLOT_STRIDE] = X; br[SL_BR_T * SLOT_STRIDE] = T_; br[SL_BR_TD * SLOT_STRIDE] = Td_; }
+        emit(std::false_type{}, P, X, tp, tvp, T_, tve, Td_, cross);
+        if (!isnan_(P) && !skew && !cross) { br[SL_BR_P * SLOT_STRIDE] = P; br[SL_BR_X * SLOT_STRIDE] = X; br[SL_BR_T * SLOT_STRIDE] = T_; br[SL_BR_TD * SLOT_STRIDE] = Td_; }
+        lcl_done = skew || cross;
+        sP = Pc; sT = Tc; sM = Mc;
+        if (PREP) s_is_td = !decltype(raw)::value;
     };
 
-    if (pc.prepend) source(pc.p, pc.t, pc.td);                             // ML: the parcel is the new level 0 (pf.py:1641-1644)
+    if (pc.prepend) source(std::false_type{}, pc.p, pc.t, pc.td, false, -1);  // ML: the parcel is the new level 0 (pf.py:1641-1644)
     constexpr bool SEARCH = PMODE == PM_MU || PMODE == PM_ML;
     int k = (int)pc.first;      // per lane for MU / ML parcels through phase A; phase B re-aligns the wavefront (below)
     // software-prefetched level loop
@@ -445,43 +466,48 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : (MO
         Td2_ = (double)*(const T *)((const char *)a.td.data + rb + voff);
     };
     if (k < a.nlev) load3(k, np_, nt_, ntd_);
-    auto next_level = [&](double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
-        P_ = np_; T2_ = nt_; M_ = ntd_;
-        if (k + 1 < a.nlev) load3(k + 1, np_, nt_, ntd_);
+    // level k out of the look-ahead buffer (NaN past the top), level k + 1 requested
+    auto next_level = [&](int kk, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
+        const bool in = kk < a.nlev;
+        P_ = in ? np_ : qnan(); T2_ = in ? nt_ : qnan(); M_ = in ? ntd_ : qnan();
+        if (kk + 1 < a.nlev) load3(kk + 1, np_, nt_, ntd_);
     };
     constexpr bool Q = HUM && !PROFILE;
-    for (; k < a.nlev; ++k) {                                              // phase A
-        if (__ballot(!lcl_done) == 0ull) break;                            // wave-uniform: everybody is above its LCL
+    for (; k <= a.nlev; ++k) {                                             // phase A
+        if (__ballot(!lcl_done || (PREP && s_is_td)) == 0ull) break;       // wave-uniform: everybody is above its LCL
         double P, T_, M_;
-        next_level(P, T_, M_);
-        cur_k = k;
-        source(P, T_, as_dewpoint<HUM>(es, P, T_, M_));
+        next_level(k, P, T_, M_);
+        source(std::true_type{}, P, T_, M_, k >= a.nlev, k);
     }
+    // Phase B: every lane is past its LCL and one level behind the loads: the level in (sP, sT, sM) is fed while the next
+    // one arrives; the iteration past the top level feeds the last one.
     if (SEARCH) {
-        // Phase B with a WAVE-UNIFORM level index.  The columns of a searching parcel start at their own levels, so after
+        // ... with a WAVE-UNIFORM level index.  The columns of a searching parcel start at their own levels, so after
         // phase A the lanes stand on different levels and every load would touch as many level rows as there are distinct
         // positions (the most-unstable kernel fetched 3.7 x its algorithmic bytes: 6.4 L2 requests per load instead of 2).
         // From here the wavefront walks up from its lowest lane and a lane sits out until the walk reaches its own level;
         // the lowest lane decides the number of iterations either way.
-        const int resume = k;
-        int ku = a.nlev;
-        for (int probe = 0; probe < a.nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
+        const int resume = k;                                              // the level this lane would load next
+        int ku = a.nlev + 1;
+        for (int probe = 0; probe <= a.nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
         if (ku < a.nlev) load3(ku, np_, nt_, ntd_);
-        for (; ku < a.nlev; ++ku) {
-            double P = np_, T_ = nt_, M_ = ntd_;
-            if (ku + 1 < a.nlev) load3(ku + 1, np_, nt_, ntd_);
-            cur_k = ku;
-            if (ku >= resume) moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+        for (; ku <= a.nlev; ++ku) {
+            double Pn, Tn, Mn;
+            next_level(ku, Pn, Tn, Mn);
+            if (ku >= resume) {
+                cur_k = ku - 1;
+                moist_node(sP, log_tab(es, sP), sT, Q ? sM : as_dewpoint<HUM>(es, sP, sT, sM), Q);
+                sP = Pn; sT = Tn; sM = Mn;
+            }
         }
     } else {
-        for (; k < a.nlev; ++k) {                                          // phase B: steady state, moist adiabat only
-            double P, T_, M_;
-            next_level(P, T_, M_);
-            cur_k = k;
+        for (; k <= a.nlev; ++k) {
+            const double P = sP, T_ = sT, M_ = sM;
+            next_level(k, sP, sT, sM);
+            cur_k = k - 1;
             moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
     }
-    if (!lcl_done) emit_lcl(qnan(), qnan(), qnan(), qnan());               // LCL above the top level: no upper bracket
     if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
     if (PROFILE) {
         for (; jout < a.prof.nlev_out; ++jout) {
