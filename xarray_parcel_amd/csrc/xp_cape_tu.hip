@@ -50,7 +50,7 @@ template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeAr
 }
 template <typename T, int PM, int MODE> void launch_t(const CapeArgs &a, bool profile, hipStream_t s) {
     if constexpr (MODE == 2) {
-        if (a.tile_counter) { launch_p<T, PM, MODE, true>(a, profile, s); return; }
+        if (a.persist) { launch_p<T, PM, MODE, true>(a, profile, s); return; }
     }
     launch_p<T, PM, MODE, false>(a, profile, s);
 }

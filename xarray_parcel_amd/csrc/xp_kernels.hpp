@@ -43,7 +43,7 @@ struct CapeArgs {
     const double *es_tab;                 // e_s(T) polynomial table in global memory (staged to LDS per block)
     const double *fam_tab;                // adiabat-family table (xp::Family; family mode)
     int32_t *flags;                       // family mode: 1 = column must be redone by the RK4 kernel
-    int32_t *tile_counter;                // family mode with persistent wavefronts: next 64-column tile to hand out
+    int persist;                          // family mode: persistent wavefronts (one workgroup per CU walks its share of the grid)
     int only_flagged;                     // RK4 fix-up pass: process flagged columns only
     ScalarsOut s;
     ProfileOut prof;
@@ -231,6 +231,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // their psi-piece: broadcast + adjacent banks, conflict-free, ~100 cycles instead of an L2 round trip per batch)
     __shared__ double s_fam[FAMILY ? FAM_SIZE : 1];
     if (FAMILY) for (int i = threadIdx.x; i < FAM_SIZE; i += blockDim.x) s_fam[i] = a.fam_tab[i];
+    __shared__ int s_next;                                                 // PERSIST: the workgroup's next tile
+    if (PERSIST && threadIdx.x == 0) s_next = (int)(blockDim.x >> 6);
     // PERSIST (family mode, large grids; the host decides): the grid is one workgroup per CU, the tables are staged once,
     // and every wavefront takes 64-column tiles from an atomic counter until the grid is done -- no staging and no drain
     // between workgroups, and whichever wavefront is free takes the next tile, so the chip walks the grid roughly in
@@ -535,22 +537,17 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     };   // column
 
     if (PERSIST) {
-        // the first tile of every wavefront is its own number (4096 wavefronts asking the one counter at the same instant
-        // serialise: ~0.25 ms measured), the later ones come from the counter as the wavefronts finish at their own times
-        const int ntiles = (int)((a.ncol + 63) >> 6);
-        const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-        int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-        while (tile < ntiles) {
+        // Every workgroup owns a contiguous share of the grid's 64-column tiles and its wavefronts take them one by one
+        // from a counter in LDS.  (One device-wide counter in memory was measured first: same-address atomics execute at
+        // the memory side one after the other, ~50 ns each -- 12 000 of them are most of c2's 0.7 ms.)
+        const int64_t ntiles = (a.ncol + 63) >> 6;
+        const int t0 = (int)(ntiles * blockIdx.x / gridDim.x), t1 = (int)(ntiles * (blockIdx.x + 1) / gridDim.x);
+        int tile = t0 + (int)(threadIdx.x >> 6);                            // s_next starts behind these (set before the staging barrier)
+        while (tile < t1) {
             const int64_t c = ((int64_t)tile << 6) + (threadIdx.x & 63);
             if (c < a.ncol) column(c);
-            if ((threadIdx.x & 63) == 0) tile = nwaves + atomicAdd(a.tile_counter, 1);
+            if ((threadIdx.x & 63) == 0) tile = t0 + atomicAdd(&s_next, 1);
             tile = __builtin_amdgcn_readfirstlane(tile);
-        }
-        // the last wavefront to leave puts the counter pair back to zero for the launch that takes this slot next (every
-        // other wavefront has made its last request before it counts itself out)
-        if ((threadIdx.x & 63) == 0 && atomicAdd(a.tile_counter + 1, 1) == nwaves - 1) {
-            atomicExch(a.tile_counter, 0);
-            atomicExch(a.tile_counter + 1, 0);
         }
     } else {
         column(c0);

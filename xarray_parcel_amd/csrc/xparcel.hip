@@ -40,10 +40,7 @@ struct State {
     double *es_tab = nullptr;   // device copy of the e_s(T) polynomial table
     double *fam_tab = nullptr;  // device copy of the adiabat-family table
     std::vector<double> fam_host;
-    int32_t *tile_ctr = nullptr;  // TILE_SLOTS x {next tile, wavefronts done}: the counters of persistent-wavefront launches; the
-    unsigned tile_seq = 0;        // kernel's last wavefront zeroes its pair again, calls take the slots in turn
 } g;
-constexpr int TILE_SLOTS = 64;    // launches in flight at once (different streams) before two would share a counter
 
 size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
 
@@ -408,11 +405,6 @@ int xp_init(int device) {
         HIP_TRY(hipMalloc((void **)&g.fam_tab, sizeof(double) * g.fam_host.size()));
         HIP_TRY(hipMemcpy(g.fam_tab, family_device_layout(g.fam_host).data(), sizeof(double) * g.fam_host.size(), hipMemcpyHostToDevice));
     }
-    if (g.init && g.device != device && g.tile_ctr) { (void)hipFree(g.tile_ctr); g.tile_ctr = nullptr; }
-    if (!g.tile_ctr) {
-        HIP_TRY(hipMalloc((void **)&g.tile_ctr, sizeof(int32_t) * 2 * TILE_SLOTS));
-        HIP_TRY(hipMemset(g.tile_ctr, 0, sizeof(int32_t) * 2 * TILE_SLOTS));
-    }
     g.device = device;
     g.init = true;
     return XP_OK;
@@ -493,17 +485,13 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
     if (o && o->moist_mode == XP_MOIST_FAMILY && a.ncol > 0) {
         HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)a.ncol, st.s));   // stream-ordered scratch: which columns need RK4
         a.flags = (int32_t *)flags;
-        // large grids run persistent wavefronts that take their tiles from a counter (k_cape_cin) which the kernel itself
-        // leaves at zero (a hipMemsetAsync per call costs 0.25 ms of stream time); XP_PERSIST_MIN_COLS: A/B
-        // Measured (scripts/run_gpu_persist.py): the searching parcels gain 4-14 % from 1 Mi columns on (uneven work per
-        // wavefront), the surface / explicit parcel 2-3 % from 4 Mi columns and loses as much below.
+        // large grids run persistent wavefronts (k_cape_cin, PERSIST); XP_PERSIST_MIN_COLS: A/B.  Measured
+        // (scripts/run_gpu_persist.py): the searching parcels gain 4-14 % from 1 Mi columns on (uneven work per wavefront),
+        // the surface / explicit parcel 2-3 % from 4 Mi columns.
         static const long long persist_env = [] { const char *e = getenv("XP_PERSIST_MIN_COLS"); return e ? atoll(e) : -1ll; }();
         const bool searching = parcel->mode == XP_PARCEL_MOST_UNSTABLE || parcel->mode == XP_PARCEL_MIXED_LAYER;
         const long long persist_min = persist_env >= 0 ? persist_env : searching ? (1ll << 19) : (4ll << 20);
-        if ((long long)a.ncol >= persist_min && a.ncol < (1ll << 36)) {
-            std::lock_guard<std::mutex> lk(g.mu);
-            a.tile_counter = g.tile_ctr + 2 * (g.tile_seq++ % TILE_SLOTS);
-        }
+        a.persist = (long long)a.ncol >= persist_min && a.ncol < (1ll << 36);
     }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
     else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
