@@ -61,14 +61,17 @@ enum { XP_MOIST_EXACT = 0, XP_MOIST_TABLE = 1, XP_MOIST_FAMILY = 2 };
    converted to dewpoint on load with the xp_dewpoint_from_specific_humidity chain (parcel_test.py:262-266), saving the
    separate pass and the (nlev, ncol) dewpoint array.  Explicit parcels (xp_parcel.dewpoint) stay dewpoints. */
 enum { XP_HUM_DEWPOINT = 0, XP_HUM_SPECIFIC = 1 };
-/* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a piecewise-polynomial table of its solutions
-   T(ln p ; psi), psi = the adiabat's temperature at 1000 hPa (8 pieces of 0.5 in ln p from 1100 hPa to ~20 hPa x 9 pieces
-   in psi from 215 to 312 K, degree 8 x 8, 46.7 KB, built at xp_init; specification: oracle/family.py).  Within 7.5e-7 K
+/* XP_MOIST_FAMILY: the same pseudo-adiabat ODE, served from a piecewise-polynomial table of its solutions: the parcel's
+   VIRTUAL temperature along the adiabat, Tv(ln p ; psi) = T (1 + 0.608 w_s(p, T)) (what pf.py:760-775 feed the CAPE / CIN
+   integration), psi = the adiabat's temperature at 1000 hPa (8 pieces of 0.5 in ln p from 1100 hPa to ~20 hPa x 9 pieces
+   in psi from 215 to 312 K, degree 8 x 8, 46.7 KB, built at xp_init; specification: oracle/family.py).  Within 1e-6 K
    of the ODE (the RK4 stepper of XP_MOIST_EXACT: 2e-5 K; MetPy's LSODA: 4e-5 ... 4e-4 K), a level costs one Horner
-   evaluation instead of an RK4 step, and all of the reference's known-answer tests pass in this mode too.  Above the
-   table's top the adiabat continues dry.  Columns whose label or LCL leave the table (psi outside 215.05 ... 311.95 K,
-   p_lcl outside ~20 ... 1100 hPa) are transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the component
-   entry points treat it as XP_MOIST_EXACT. */
+   evaluation instead of an RK4 step, and all of the reference's known-answer tests pass in this mode too.  The parcel
+   TEMPERATURE, where asked for (profile output, virtual_temperature_correction off), is the T with that virtual
+   temperature at that pressure (Newton on the reference's own formula).  Above the table's top the adiabat continues dry.
+   Columns whose label or LCL leave the table (psi outside 215.05 ... 311.95 K, p_lcl outside ~20 ... 1100 hPa) are
+   transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the component entry points treat it as
+   XP_MOIST_EXACT. */
 enum { XP_LCL_INTERP_LINEAR = 0, XP_LCL_INTERP_LOG = 1 };
 
 /* error codes */
