@@ -130,10 +130,13 @@ __device__ __attribute__((noinline)) double crossing_x_ref(double y, double yp, 
 // ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
 // The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
 // exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a table into LDS:
-// 193 one-kelvin intervals over 137..330 K, a degree-7 polynomial in r = T - centre each (Chebyshev
-// interpolant of Bolton's formula built in long double by xp_init; relative error < 3e-15), stored
-// coefficient-major so that the lanes of a wavefront -- whose temperatures fall in different intervals --
-// hit different LDS banks.  Out-of-range or NaN temperatures take the formula.
+// 193 one-kelvin intervals over 137..330 K, a degree-5 polynomial in r = T - centre each (Chebyshev
+// interpolant of Bolton's formula built in long double by xp_init), stored coefficient-major so that the lanes of a
+// wavefront -- whose temperatures fall in different intervals -- hit different LDS banks.  Out-of-range or NaN
+// temperatures take the formula.  Relative error 1.5e-13 above 230 K, 1.6e-12 above 200 K, 9e-10 at 137 K (where e_s is
+// 1e-7 hPa): below 1e-12 K in any virtual temperature, seven orders under the parity bar.  (Round 1 carried degree 7,
+// 6e-14 everywhere: two more fp64 instructions and two more LDS reads per evaluation for digits nothing consumes -- 2 %
+// of the family kernel, 5 % of the RK4 one, measured in a same-box A/B.  XP_ES_DEG = 6 / 7 still build.)
 constexpr double ES_T_LO = 137.0;
 // Row stride 257 doubles: (a) more than the 255 x 8 B reach of ds_read2_b64 and not a multiple of 64, so every
 // coefficient is its own ds_read_b64 (2 LDS cycles, banks (a/4) mod 64) instead of half a ds_read2_b64 (8 cycles per
@@ -142,7 +145,7 @@ constexpr double ES_T_LO = 137.0;
 // carry the ln table there (1/c_i and ln c_i for 64 mantissa intervals), and the last row ends after its 193 entries
 // -- 15.9 KB in all, which together with the scan's LDS slots lets four workgroups share a CU.
 #ifndef XP_ES_DEG
-#define XP_ES_DEG 7
+#define XP_ES_DEG 5
 #endif
 constexpr int ES_N = 193, ES_DEG = XP_ES_DEG, ES_STRIDE = 257, ES_TAB = ES_DEG * ES_STRIDE + ES_N;
 constexpr int LOG_N = 64, LOG_OFF = ES_N;           // ln table: tb[LOG_OFF + i] = 1/c_i, tb[ES_STRIDE + LOG_OFF + i] = ln c_i
@@ -162,7 +165,7 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     const double *c = tb + i;
     double p = c[ES_DEG * ES_STRIDE];
     if (ES_DEG >= 7) p = __builtin_fma(p, r, c[6 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[5 * ES_STRIDE]);
+    if (ES_DEG >= 6) p = __builtin_fma(p, r, c[5 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[4 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[3 * ES_STRIDE]);
     p = __builtin_fma(p, r, c[2 * ES_STRIDE]);

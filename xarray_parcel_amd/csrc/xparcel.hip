@@ -44,7 +44,7 @@ struct State {
 
 size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
 
-// e_s(T) table for xp::es_tab: per 1 K interval the degree-7 interpolant of Bolton's formula at Chebyshev nodes,
+// e_s(T) table for xp::es_tab: per 1 K interval the degree-ES_DEG interpolant of Bolton's formula at Chebyshev nodes,
 // monomial coefficients in r = T - centre, built in long double; layout [coefficient][interval].
 void build_es_table(double *out) {
     using LD = long double;
