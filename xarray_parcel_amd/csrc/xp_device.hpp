@@ -187,16 +187,25 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
 XP_DEV bool in_table(double t, double margin) { return (t >= ES_T_LO + margin) && (t < ES_T_LO + (double)ES_N - margin); }
 // ln(x) from the LDS table that follows the e_s table: x = 2^e m, m in [0.5,1) = c_i (1 + r), |r| < 2^-7;
 // ln x = e ln2 + ln c_i + log1p(r), log1p by its series to r^7 (< 2e-18).  Positive finite x (NaN -> NaN).
-XP_DEV double log_tab(const double *tb, double x) {
+// SHORT: log1p(r) through r^5 (|r| <= 2^-7: the next term, r^6 / 6, is 3.6e-14 -- 5e-15 of ln p).  For the ln p of the
+// level loop: 3e-9 J/kg of CAPE, 4e-11 hPa of a crossing pressure at most, two fp64 instructions less per level (1.5 % of
+// the family kernel, same-box A/B).  NOT for the q -> dewpoint chain, whose logarithm feeds a dewpoint that must compare
+// equal to the temperature on saturated levels to the last bit.
+template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) {
     const double *lt = tb + LOG_OFF;
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);
     int i = (int)(m * 128.0) - 64;
     i = i < 0 ? 0 : (i > LOG_N - 1 ? LOG_N - 1 : i);
     double r = __builtin_fma(m, lt[i], -1.0);
-    double q = fma_sc(1.0 / 7.0, r, -1.0 / 6.0);
-    q = fma_sc(q, r, 0.2);
-    q = fma_sc(q, r, -0.25);
+    double q;
+    if (SHORT) {
+        q = fma_sc(0.2, r, -0.25);
+    } else {
+        q = fma_sc(1.0 / 7.0, r, -1.0 / 6.0);
+        q = fma_sc(q, r, 0.2);
+        q = fma_sc(q, r, -0.25);
+    }
     q = fma_sc(q, r, 1.0 / 3.0);
     q = __builtin_fma(q, r, -0.5);
     q = __builtin_fma(q, r, 1.0);

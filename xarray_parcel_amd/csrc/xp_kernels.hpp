@@ -298,7 +298,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // level gets, so that the surface parcel reproduces its level bit for bit (T0 * exp(0)) -- the reference's lfc_el
     // branches on that exact equality (pf.py:1117-1120).
     const double x_lcl = log(l.p);
-    const double x0 = (pc.p == l.p) ? x_lcl : log_tab(es, pc.p);
+    const double x0 = (pc.p == l.p) ? x_lcl : log_tab<true>(es, pc.p);
 
     Scan sc; sc.init(l.p, x_lcl, pos_neg, s_slot + threadIdx.x);
     sc.slot[SL_LCL_T * SLOT_STRIDE] = vtc ? l.tv : l.t;                  // pf.py:1442 / 1461
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         double Td_ = (decltype(raw)::value && !(PREP && skew && s_is_td)) ? as_dewpoint<HUM>(es, P, T_, M_) : M_;
         if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
         cur_k = skew ? kc - 1 : kc;
-        double X = log_tab(es, P);
+        double X = log_tab<true>(es, P);
         X = (P == l.p) ? x_lcl : X;
         const bool cross = !skew && (last || P < l.p);
         if (isnan_(P) && !skew && !last) status |= 4;                      // NaN pressure below the LCL (see xparcel.h)
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             next_level(ku, Pn, Tn, Mn);
             if (ku >= resume) {
                 cur_k = ku - 1;
-                moist_node(sP, log_tab(es, sP), sT, Q ? sM : as_dewpoint<HUM>(es, sP, sT, sM), Q);
+                moist_node(sP, log_tab<true>(es, sP), sT, Q ? sM : as_dewpoint<HUM>(es, sP, sT, sM), Q);
                 sP = Pn; sT = Tn; sM = Mn;
             }
         }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             const double P = sP, T_ = sT, M_ = sM;
             next_level(k, sP, sT, sM);
             cur_k = k - 1;
-            moist_node(P, log_tab(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+            moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
     }
     if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
