@@ -167,6 +167,32 @@ def test_explicit_parcel_and_ragged_shapes():
     assert got['cape'].shape == (0,)
 
 
+@pytest.mark.parametrize('moist', ['exact', 'family'])
+def test_truncated_columns_lcl_at_and_above_the_top(moist):
+    """Phase A's edge cases: only the lowest 1 ... 8 levels of a 64-level grid, so that for many columns the LCL lies above
+    the top level (its node is fed in the iteration past the top, with no upper bracket: NaN environment), is bracketed
+    by the last two levels (the crossing level is the last one and waits for the flush iteration), or is the parcel's
+    own level (saturated).  Scalars for every parcel, and the profile rows (count, order, NaN pattern) for the surface
+    and the mixed-layer parcel."""
+    full = synth.columns(nlev=64, ncol=6000, seed=41, nan_fraction=0.08, dtype=np.float64)
+    for nlev in (1, 2, 3, 5, 8):
+        p, t, td = (np.ascontiguousarray(v[:nlev]) for v in full)
+        for parcel in ('surface', 'most_unstable', 'mixed_layer'):
+            got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist)
+            ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if moist == 'exact' else 'family')
+            above = np.nansum(ref['lcl_pressure'] < np.nanmin(p, axis=0))
+            assert parcel != 'surface' or above > 100                         # the case this test is about is in the sample
+            _compare(got, ref, np.float64, 1e-6)
+        for parcel in ('surface', 'mixed_layer'):
+            got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want_profile=True)
+            ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if moist == 'exact' else 'family', want_profile=True)
+            for k in ref['profile']:
+                a, b = got['profile'][k], ref['profile'][k]
+                assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), (nlev, parcel, k)
+                ok = ~np.isnan(b)
+                assert not ok.any() or np.max(np.abs(a[ok] - b[ok])) <= 1e-8, (nlev, parcel, k)
+
+
 def test_nan_pressure_levels():
     """A NaN PRESSURE inside a column (outside the reference's input contract, README.md:9).
     Above the LCL the kernel follows the reference (the level is an all-NaN node).  Below the LCL the reference's
