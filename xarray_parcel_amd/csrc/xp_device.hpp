@@ -573,30 +573,40 @@ struct Family {
         if (!(fabs(psi - psi0) <= FAM_MARGIN)) bad = true;
         s = bad ? 0.0 : (psi - mid) * inv_h;
         load_piece(j0);
+        if (bad) poison();
     }
     // VIRTUAL temperature of the column's parcel at ln p = X (X <= x_lcl; levels normally come with decreasing X).
     // x-piece j holds z in (-1, 1]: the fast path only tests that (the piece index itself is recovered from m4 when a
     // lane has to move, with the oracle's floor rule).
     XP_DEV double at(double X) {
         double z = __builtin_fma(2.0 / FAM_WX, X, m4);
-        double dry = 1.0;
-        bool move = !(z > -1.0 && z <= 1.0) && !bad;                                // NaN X -> move (and nothing to do)
+        // a NaN z stays put: a NaN pressure, or a column outside the table (poisoned below: its nine coefficients and m4
+        // are NaN, so it evaluates to NaN without a test of its own on the per-level path)
+        bool move = (z <= -1.0) || (z > 1.0);
         if (__builtin_amdgcn_ballot_w64(move) != 0ull) {                            // rare: another x-piece, or off the table
             // every lane of the wavefront reloads -- the ones that stay put their current piece -- so that the nine
             // coefficients are plainly overwritten instead of merged per lane (which would keep old and new alive together)
             double u = __builtin_fma(-(1.0 / FAM_WX), X, FAM_XHI * (1.0 / FAM_WX)); // (XHI - X) / WX
-            bool go = move && !isnan_(X);
+            bool go = move;
             if (go && u < 0.0) { bad = true; go = false; }                          // p > 1100 hPa
             int jn = (int)u;
             bool top = go && jn > FAM_NPX - 1;                                      // above the table top: dry continuation
             int jcur = (int)__builtin_rint(__builtin_fma(m4, 0.5, FAM_XHI * (1.0 / FAM_WX) - 0.5));
             int j = go ? (jn > FAM_NPX - 1 ? FAM_NPX - 1 : jn) : jcur;
-            load_piece(j);
+            load_piece(bad ? 0 : j);
+            if (bad) poison();
             z = __builtin_fma(2.0 / FAM_WX, X, m4);
-            if (top) { dry = fexp(KAPPA * (X - FAM_XLO)); z = -1.0; }
+            if (__builtin_amdgcn_ballot_w64(top) != 0ull) {
+                double v = horner(top ? -1.0 : z);
+                return top ? v * fexp(KAPPA * (X - FAM_XLO)) : v;
+            }
         }
-        double v = horner(z) * dry;
-        return bad ? qnan() : v;
+        return horner(z);
+    }
+    XP_DEV void poison() {
+#pragma unroll
+        for (int n = 0; n <= FAM_ND; ++n) c[n] = qnan();
+        m4 = qnan();
     }
 };
 
