@@ -467,19 +467,20 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         T2_ = (double)*(const T *)((const char *)a.t.data + rb + voff);
         Td2_ = (double)*(const T *)((const char *)a.td.data + rb + voff);
     };
-    if (k < a.nlev) load3(k, np_, nt_, ntd_);
+    const int nlev = (int)a.nlev;                                          // the host checks nlev < 2^31: 32-bit scalar compares in the loops
+    if (k < nlev) load3(k, np_, nt_, ntd_);
     // level k out of the look-ahead buffer (NaN past the top), level k + 1 requested
     auto next_level = [&](int kk, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
-        const bool in = kk < a.nlev;
+        const bool in = kk < nlev;
         P_ = in ? np_ : qnan(); T2_ = in ? nt_ : qnan(); M_ = in ? ntd_ : qnan();
-        if (kk + 1 < a.nlev) load3(kk + 1, np_, nt_, ntd_);
+        if (kk + 1 < nlev) load3(kk + 1, np_, nt_, ntd_);
     };
     constexpr bool Q = HUM && !PROFILE;
-    for (; k <= a.nlev; ++k) {                                             // phase A
+    for (; k <= nlev; ++k) {                                             // phase A
         if (__ballot(!lcl_done || (PREP && s_is_td)) == 0ull) break;       // wave-uniform: everybody is above its LCL
         double P, T_, M_;
         next_level(k, P, T_, M_);
-        source(std::true_type{}, P, T_, M_, k >= a.nlev, k);
+        source(std::true_type{}, P, T_, M_, k >= nlev, k);
     }
     // Phase B: every lane is past its LCL and one level behind the loads: the level in (sP, sT, sM) is fed while the next
     // one arrives; the iteration past the top level feeds the last one.
@@ -490,10 +491,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // From here the wavefront walks up from its lowest lane and a lane sits out until the walk reaches its own level;
         // the lowest lane decides the number of iterations either way.
         const int resume = k;                                              // the level this lane would load next
-        int ku = a.nlev + 1;
-        for (int probe = 0; probe <= a.nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
-        if (ku < a.nlev) load3(ku, np_, nt_, ntd_);
-        for (; ku <= a.nlev; ++ku) {
+        int ku = nlev + 1;
+        for (int probe = 0; probe <= nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
+        if (ku < nlev) load3(ku, np_, nt_, ntd_);
+        for (; ku <= nlev; ++ku) {
             double Pn, Tn, Mn;
             next_level(ku, Pn, Tn, Mn);
             if (ku >= resume) {
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             }
         }
     } else {
-        for (; k <= a.nlev; ++k) {
+        for (; k <= nlev; ++k) {
             const double P = sP, T_ = sT, M_ = sM;
             next_level(k, sP, sT, sM);
             cur_k = k - 1;

@@ -235,7 +235,8 @@ void build_family_table(double *tab) {
 int check_view(const xp_view *v, const char *name) {
     if (!v || !v->data) return fail(XP_E_ARG, "%s: null view", name);
     if (v->dtype != XP_F32 && v->dtype != XP_F64) return fail(XP_E_ARG, "%s: dtype must be XP_F32 or XP_F64", name);
-    if (v->nlev < 1 || v->ncol < 0) return fail(XP_E_ARG, "%s: bad shape (%lld, %lld)", name, (long long)v->nlev, (long long)v->ncol);
+    if (v->nlev < 1 || v->ncol < 0 || v->nlev >= (1ll << 30))
+        return fail(XP_E_ARG, "%s: bad shape (%lld, %lld)", name, (long long)v->nlev, (long long)v->ncol);
     if (v->mem == XP_MEM_HOST && !(v->col_stride == 1 && v->lev_stride == v->ncol))
         return fail(XP_E_ARG, "%s: host views must be dense (nlev, ncol) C-order", name);
     return 0;
