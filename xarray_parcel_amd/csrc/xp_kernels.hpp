@@ -456,24 +456,28 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     constexpr bool SEARCH = PMODE == PM_MU || PMODE == PM_ML;
     int k = (int)pc.first;      // per lane for MU / ML parcels through phase A; phase B re-aligns the wavefront (below)
     // software-prefetched level loop
-    // Level loads: when the three views share their strides and a column's byte offset inside a level row fits 32 bits
-    // (the host checks; always so for (lev, y, x) grids), one 32-bit per-lane offset serves all three arrays and the row
-    // base is scalar -- instead of three 64-bit per-lane base addresses held through the loop (5 VGPRs less).
-    const uint32_t voff = (uint32_t)((uint64_t)c * (uint64_t)a.p.cs * sizeof(T));
+    // Three per-lane row pointers that WALK up the levels: set once (64-bit multiply-add, a quarter-rate instruction),
+    // then advanced by the row stride with two full-rate adds per array and level.
+    const int64_t lane_off = (int64_t)c * a.p.cs * (int64_t)sizeof(T), row_step = a.p.ls * (int64_t)sizeof(T);
+    const char *lp = nullptr, *lt = nullptr, *ld_ = nullptr;
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
-    auto load3 = [&](int64_t kk, double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
-        size_t rb = (size_t)kk * (size_t)a.p.ls * sizeof(T);
-        P_ = (double)*(const T *)((const char *)a.p.data + rb + voff);
-        T2_ = (double)*(const T *)((const char *)a.t.data + rb + voff);
-        Td2_ = (double)*(const T *)((const char *)a.td.data + rb + voff);
+    auto seek = [&](int64_t kk) __attribute__((always_inline)) {             // the next load3() reads level kk
+        const int64_t o = kk * row_step + lane_off;
+        lp = (const char *)a.p.data + o; lt = (const char *)a.t.data + o; ld_ = (const char *)a.td.data + o;
+    };
+    auto load3 = [&](double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
+        P_ = (double)*(const T *)lp; T2_ = (double)*(const T *)lt; Td2_ = (double)*(const T *)ld_;
+        lp += row_step; lt += row_step; ld_ += row_step;
+        asm volatile("" : "+v"(lp), "+v"(lt), "+v"(ld_));                  // (keeps the walk: no re-derivation from the level index)
     };
     const int nlev = (int)a.nlev;                                          // the host checks nlev < 2^31: 32-bit scalar compares in the loops
-    if (k < nlev) load3(k, np_, nt_, ntd_);
+    seek(k);
+    if (k < nlev) load3(np_, nt_, ntd_);
     // level k out of the look-ahead buffer (NaN past the top), level k + 1 requested
     auto next_level = [&](int kk, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
         const bool in = kk < nlev;
         P_ = in ? np_ : qnan(); T2_ = in ? nt_ : qnan(); M_ = in ? ntd_ : qnan();
-        if (kk + 1 < nlev) load3(kk + 1, np_, nt_, ntd_);
+        if (kk + 1 < nlev) load3(np_, nt_, ntd_);
     };
     constexpr bool Q = HUM && !PROFILE;
     for (; k <= nlev; ++k) {                                             // phase A
@@ -493,7 +497,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         const int resume = k;                                              // the level this lane would load next
         int ku = nlev + 1;
         for (int probe = 0; probe <= nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
-        if (ku < nlev) load3(ku, np_, nt_, ntd_);
+        seek(ku);
+        if (ku < nlev) load3(np_, nt_, ntd_);
         for (; ku <= nlev; ++ku) {
             double Pn, Tn, Mn;
             next_level(ku, Pn, Tn, Mn);
