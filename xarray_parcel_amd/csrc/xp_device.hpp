@@ -130,7 +130,7 @@ __device__ __attribute__((noinline)) double crossing_x_ref(double y, double yp, 
 // ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
 // The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
 // exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a table into LDS:
-// 193 one-kelvin intervals over 137..330 K, a degree-5 polynomial in r = T - centre each (Chebyshev
+// 193 one-kelvin intervals over 137..330 K, a degree-5 polynomial in r = T - left edge each (Chebyshev
 // interpolant of Bolton's formula built in long double by xp_init), stored coefficient-major so that the lanes of a
 // wavefront -- whose temperatures fall in different intervals -- hit different LDS banks.  Out-of-range or NaN
 // temperatures take the formula.  Relative error 1.5e-13 above 230 K, 1.6e-12 above 200 K, 9e-10 at 137 K (where e_s is
@@ -143,7 +143,7 @@ constexpr double ES_T_LO = 137.0;
 // pair, banks mod 32: measured 48 % of all LDS cycles were bank conflicts with the merged reads); (b) odd, so that
 // row c is rotated by c banks against row 0.  193 intervals (137 ... 330 K) leave 64 spare columns per row: rows 0 and 1
 // carry the ln table there (1/c_i and ln c_i for 64 mantissa intervals), and the last row ends after its 193 entries
-// -- 15.9 KB in all, which together with the scan's LDS slots lets four workgroups share a CU.
+// -- 11.8 KB in all (degree 5), which together with the scan's LDS slots lets four workgroups share a CU.
 #ifndef XP_ES_DEG
 #define XP_ES_DEG 5
 #endif
@@ -161,7 +161,7 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
         ok = (u >= 0.0) && (u < (double)ES_N);
         i = i < 0 ? 0 : (i > ES_N - 1 ? ES_N - 1 : i);
     }
-    double r = u - ((double)i + 0.5);
+    double r = __builtin_amdgcn_fract(u);            // the polynomials are in T - (left edge of the interval): no way back from the index
     const double *c = tb + i;
     double p = c[ES_DEG * ES_STRIDE];
     if (ES_DEG >= 7) p = __builtin_fma(p, r, c[6 * ES_STRIDE]);

@@ -45,17 +45,17 @@ struct State {
 size_t esize(int dtype) { return dtype == XP_F64 ? 8 : 4; }
 
 // e_s(T) table for xp::es_tab: per 1 K interval the degree-ES_DEG interpolant of Bolton's formula at Chebyshev nodes,
-// monomial coefficients in r = T - centre, built in long double; layout [coefficient][interval].
+// monomial coefficients in r = T - left edge (what v_fract_f64 delivers), built in long double; layout [coefficient][interval].
 void build_es_table(double *out) {
     using LD = long double;
     const int n = xp::ES_DEG + 1;
     const LD pi = 3.14159265358979323846264338327950288L;
     for (int i = 0; i < xp::ES_N; ++i) {
-        LD centre = (LD)xp::ES_T_LO + (LD)i + 0.5L;
+        LD edge = (LD)xp::ES_T_LO + (LD)i;
         LD A[8][9];
         for (int k = 0; k < n; ++k) {
-            LD r = 0.5L * cosl(pi * ((LD)k + 0.5L) / (LD)n);
-            LD t = centre + r;
+            LD r = 0.5L + 0.5L * cosl(pi * ((LD)k + 0.5L) / (LD)n);
+            LD t = edge + r;
             LD v = 1.0L;
             for (int j = 0; j < n; ++j) { A[k][j] = v; v *= r; }
             A[k][n] = 6.112L * expl(17.67L * (t - 273.15L) / (t - 29.65L));
