@@ -208,23 +208,24 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 //
 // The level loop runs in two wave-uniform phases.  Phase A (some lane of the wavefront is still at or below
 // its LCL; decided with a ballot) carries the full logic: dry or moist parcel, bracketing levels for the
-// environment at the LCL, emission of the LCL node.  Phase B (every lane above its LCL) is the steady state
-// and only advances the moist adiabat, so the LCL machinery costs nothing for most of the column.
+// environment at the LCL, the LCL node -- one node per lane and iteration, see `source` below.  Phase B (every lane
+// above its LCL) is the steady state and only advances the moist adiabat, so the LCL machinery costs nothing for most
+// of the column.
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
 // DEF: the reference's default option set, virtual-temperature correction on and sign-filtered sums (pf.py:1396, 1293),
 // as compile-time constants: the selects and scalar registers the run-time switches cost in the level loop go away.
-// Instantiated for the CAPE/CIN-only, dewpoint-input kernels; every other combination takes DEF = false.
+// Instantiated for the dewpoint-input kernels of modes 0 / 1; family mode and every other combination take DEF = false
+// (xp_cape_tu.hip has the dispatch rule and why).
 // LEAN (with DEF): the caller wants neither LFC / EL temperatures nor interval indices (the bench, the gather of a
 // multi-GPU run): they are not tracked, see Scan::node.
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF, bool LEAN, bool PERSIST>
 __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MODE == 2 ? 3 : PROFILE ? 4 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
-    // Occupancy: the surface-parcel CAPE/CIN kernel needs 127 VGPRs on its own (4 waves/SIMD; forcing it changes the
-    // allocation for the worse); ML / MU / explicit sit at 130-138 and are held to 128 (ML without spills, MU / explicit
-    // with 24 B of scratch or none, still a net gain); profile output and the family mode stay at 3 waves (168).  The
-    // bound only steers the allocator (with q input the surface kernel lands on 126 under "3" and on 129 under "1");
-    // tests/test_kernel_resources.py checks what comes out.
+    // Occupancy: four wavefronts per SIMD everywhere -- the family translation units through their 1024-thread workgroups
+    // (one per CU), the others through the bound (256-thread workgroups, four per CU).  The bound only steers the
+    // allocator (the dewpoint-input surface kernel of modes 0 / 1 lands below 128 VGPRs on its own and is allocated worse
+    // when forced); tests/test_kernel_resources.py checks what comes out.
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     __shared__ double s_es[LDS_TAB];
     // family mode: the coefficient table lives in LDS too (46.7 KB; read 81 doubles at a time by lanes that differ only in
