@@ -460,14 +460,18 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // Three per-lane row pointers that WALK up the levels: set once (64-bit multiply-add, a quarter-rate instruction),
     // then advanced by the row stride with two full-rate adds per array and level.
     const int64_t lane_off = (int64_t)c * a.p.cs * (int64_t)sizeof(T), row_step = a.p.ls * (int64_t)sizeof(T);
-    const char *lp = nullptr, *lt = nullptr, *ld_ = nullptr;
+    // (address space 1 = global, spelled out: behind the asm barrier below the compiler would otherwise fall back to
+    // flat loads, which also count against the LDS counter and so make every LDS wait a memory wait)
+    typedef const char __attribute__((address_space(1))) *GPtr;
+    GPtr lp = nullptr, lt = nullptr, ld_ = nullptr;
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     auto seek = [&](int64_t kk) __attribute__((always_inline)) {             // the next load3() reads level kk
         const int64_t o = kk * row_step + lane_off;
-        lp = (const char *)a.p.data + o; lt = (const char *)a.t.data + o; ld_ = (const char *)a.td.data + o;
+        lp = (GPtr)a.p.data + o; lt = (GPtr)a.t.data + o; ld_ = (GPtr)a.td.data + o;
     };
     auto load3 = [&](double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
-        P_ = (double)*(const T *)lp; T2_ = (double)*(const T *)lt; Td2_ = (double)*(const T *)ld_;
+        typedef const T __attribute__((address_space(1))) *GT;
+        P_ = (double)*(GT)lp; T2_ = (double)*(GT)lt; Td2_ = (double)*(GT)ld_;
         lp += row_step; lt += row_step; ld_ += row_step;
         asm volatile("" : "+v"(lp), "+v"(lt), "+v"(ld_));                  // (keeps the walk: no re-derivation from the level index)
     };
