@@ -195,8 +195,7 @@ template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) 
     const double *lt = tb + LOG_OFF;
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);
-    int i = (int)(m * 128.0) - 64;
-    i = i < 0 ? 0 : (i > LOG_N - 1 ? LOG_N - 1 : i);
+    int i = (__double2hiint(x) >> 14) & (LOG_N - 1);       // the top six fraction bits = floor(128 m) - 64 (one v_bfe_u32)
     double r = __builtin_fma(m, lt[i], -1.0);
     double q;
     if (SHORT) {
