@@ -143,7 +143,8 @@ typedef struct {
 
 /* Optional lifted profile with the LCL inserted as an extra level (pf.py:806-931): six
    (nlev_out, ncol) arrays, nlev_out >= nlev + 1.  For MU / ML parcels the profile is re-based
-   (levels below the parcel removed, pf.py:1551-1553, 1636-1644) and padded with NaN on top. */
+   (levels below the parcel removed, pf.py:1551-1553, 1636-1644) and padded with NaN on top.  Any of the six
+   pointers may be NULL: that array is not written (lifted_index, pf.py:1722, reads three of them). */
 typedef struct {
     void *pressure, *temperature, *virtual_temperature;                 /* parcel */
     void *environment_temperature, *environment_virtual_temperature, *environment_dewpoint;

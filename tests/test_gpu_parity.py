@@ -153,6 +153,21 @@ def test_profile_vs_oracle():
             assert np.max(np.abs(a[ok] - b[ok])) <= 1e-8, (parcel, k, np.max(np.abs(a[ok] - b[ok])))
 
 
+def test_profile_subset_writes_only_what_is_named():
+    """xp_profile_out pointers may be NULL: a subset of the six profile arrays (what lifted_index reads) equals the same
+    arrays of the full request, and the scalars do not change."""
+    p, t, td = synth.columns(nlev=40, ncol=3000, seed=13, nan_fraction=0.08, dtype=np.float64)
+    for parcel, moist in (('surface', 'exact'), ('mixed_layer', 'family'), ('most_unstable', 'exact')):
+        full = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want_profile=True)
+        part = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want_profile=xa.LIFTED_INDEX_VARS)
+        assert set(part['profile']) == set(xa.LIFTED_INDEX_VARS)
+        for k in xa.LIFTED_INDEX_VARS:
+            assert np.array_equal(part['profile'][k], full['profile'][k], equal_nan=True), (parcel, k)
+        for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+            assert np.array_equal(part[k], full[k], equal_nan=True), (parcel, k)
+        assert np.array_equal(xa.lifted_index(part['profile']), xa.lifted_index(full['profile']), equal_nan=True)
+
+
 def test_explicit_parcel_and_ragged_shapes():
     # ncol not a multiple of the wavefront / block, 1 column, 1 level
     for nlev, ncol in ((30, 1), (30, 63), (30, 257), (2, 100), (1, 70)):

@@ -160,6 +160,8 @@ def set_moist_lapse(mode):
 def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=None, parcel_values=None,
                      want_profile=False, want=None, moist=None, **kwargs):
     """pf.py:1394-1475 with the three drivers.  Returns a dict of per-column arrays (and 'profile').
+    want_profile: True for the six profile arrays of pf.py:806-931, or an iterable of their names for a subset (the ones
+    not named are neither allocated nor written: lifted_index needs three of the six).
     humidity='specific' (keyword): `dewpoint` holds specific humidity [kg/kg] and is converted on load
     (parcel_test.py:262-266 fused into the pass)."""
     (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
@@ -189,7 +191,9 @@ def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=No
         po = L.ProfileOut()
         po.dtype, po.mem, po.nlev_out, po.lev_stride, po.col_stride = p.xp_dtype, p.mem, nlev + 1, ncol, 1
         prof = {}
-        for k in L.PROFILE_VARS:
+        pvars = L.PROFILE_VARS if want_profile is True else tuple(want_profile)
+        assert all(k in L.PROFILE_VARS for k in pvars), f'profile variables are {L.PROFILE_VARS}'
+        for k in pvars:
             arr, ptr = _alloc((nlev + 1, ncol), dt, dev, p)
             setattr(po, k, ptr)
             prof[k] = arr
@@ -505,6 +509,9 @@ def deep_convective_index(pressure, temperature, dewpoint, lifted_index):
     return t850 + td850 - lifted_index
 
 
+LIFTED_INDEX_VARS = ('pressure', 'temperature', 'environment_temperature')      # the profile rows lifted_index() reads
+
+
 def lifted_index(profile):
     """pf.py:1722: environment minus parcel temperature at 500 hPa (log-p interpolation of the profile)."""
     env = interp_level(profile['pressure'], profile['environment_temperature'], 500.0, log=True)
@@ -571,7 +578,7 @@ def conv_properties(dat, ignore_nans=False):
     p, t, q, z = to(p), to(t), to(q), to(dat['height_asl'])
     valid = ~(xp.isnan(td).any(0) | xp.isnan(p).any(0) | xp.isnan(t).any(0) | xp.isnan(q).any(0))
     out = {}
-    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, want_profile=True)
+    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, want_profile=LIFTED_INDEX_VARS)
     out['mu_cape'], out['mu_cin'] = mu['cape'], mu['cin']
     e = 6.112 * xp.exp(17.67 * (mu['parcel_dewpoint'] - 273.15) / (mu['parcel_dewpoint'] - 29.65))
     w = L_EPS * e / (mu['parcel_pressure'] - e)                       # specific_humidity_from_dewpoint -> mixing ratio
@@ -579,7 +586,7 @@ def conv_properties(dat, ignore_nans=False):
     out['mu_mixing_ratio'] = qs / (1.0 - qs)
     out['mu_lifted_index'] = lifted_index(mu['profile'])
     for depth in (100, 50):
-        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, want_profile=True)
+        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, want_profile=LIFTED_INDEX_VARS)
         out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
         out[f'mixed_{depth}_lifted_index'] = lifted_index(ml['profile'])
     for pre in ('mu', 'mixed_100', 'mixed_50'):
@@ -610,7 +617,7 @@ def min_conv_properties(dat):
         dat = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).cuda() for k, v in dat.items()}
     p, t, z = dat['pressure'], dat['temperature'], dat['height_asl']
     td = dewpoint_from_specific_humidity(p, t, dat['specific_humidity'])
-    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, want_profile=True)
+    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, want_profile=LIFTED_INDEX_VARS)
     out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': lifted_index(ml['profile']),
            'lapse_rate_700_500': lapse_rate(p, t, z), 'temp_500': isobar_temperature(p, t, 500.0),
            'freezing_level': freezing_level_height(t, z), 'melting_level': melting_level_height(p, t, td, z)[0]}
