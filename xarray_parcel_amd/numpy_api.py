@@ -589,8 +589,10 @@ def conv_properties(dat, ignore_nans=False):
         ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, want_profile=LIFTED_INDEX_VARS)
         out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
         out[f'mixed_{depth}_lifted_index'] = lifted_index(ml['profile'])
+    t850 = interp_level(p, t, 850.0, log=True) - 273.15                # pf.py:1830, the part of the DCI the three share
+    td850 = interp_level(p, td, 850.0, log=True) - 273.15
     for pre in ('mu', 'mixed_100', 'mixed_50'):
-        out[pre + '_dci'] = deep_convective_index(p, t, td, out[pre + '_lifted_index'])
+        out[pre + '_dci'] = t850 + td850 - out[pre + '_lifted_index']
     out['lapse_rate_700_500'] = lapse_rate(p, t, z)
     out['temp_500'] = isobar_temperature(p, t, 500.0)
     out['freezing_level'] = freezing_level_height(t, z)
