@@ -150,6 +150,12 @@ typedef struct {
     void *environment_temperature, *environment_virtual_temperature, *environment_dewpoint;
     int32_t dtype, mem;
     int64_t nlev_out, lev_stride, col_stride;
+    /* lifted_index (pf.py:1722): environment minus parcel temperature of THIS profile at `lifted_index_pressure` hPa
+       (the reference: 500), by the log_interp rule of pf.py:1813 applied to the profile's rows -- ncol values of the
+       profile's dtype / mem, written in the same pass; NULL = not wanted.  With all six arrays NULL the pass costs
+       little more than CAPE / CIN alone. */
+    void *lifted_index;
+    double lifted_index_pressure;
 } xp_profile_out;
 
 /* reference-format moist-adiabat lookup tables (pf.py:447-523), host memory, copied to the device */

@@ -168,6 +168,36 @@ def test_profile_subset_writes_only_what_is_named():
         assert np.array_equal(xa.lifted_index(part['profile']), xa.lifted_index(full['profile']), equal_nan=True)
 
 
+@pytest.mark.parametrize('moist', ['exact', 'family'])
+def test_lifted_index_in_the_same_pass(moist):
+    """xp_profile_out.lifted_index: pf.py:1722 of the lifted profile computed while the scan passes 500 hPa, against the
+    composition it replaces (write the profile, log_interp two of its rows: numpy_api.lifted_index) and against the
+    oracle's; grids whose top is below / whose surface is above the level give NaN as the reference's log_interp does."""
+    from oracle import parcel_oracle as po
+    p, t, td = synth.columns(nlev=40, ncol=3000, seed=17, nan_fraction=0.08, dtype=np.float64)
+    for parcel, kw in (('surface', {}), ('mixed_layer', {'depth': 100}), ('most_unstable', {'depth': 250})):
+        full = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want_profile=True, **kw)
+        got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, lifted_index_at=500.0, **kw)
+        assert 'profile' not in got
+        ref = xa.lifted_index(full['profile'])
+        li = got['lifted_index']
+        assert np.array_equal(np.isnan(li), np.isnan(ref)), parcel
+        ok = ~np.isnan(ref)
+        assert ok.sum() > 2000 and np.max(np.abs(li[ok] - ref[ok])) <= 1e-9, (parcel, np.max(np.abs(li[ok] - ref[ok])))
+        for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+            assert np.array_equal(got[k], full[k], equal_nan=True), (parcel, k)
+    # a grid that stops below 500 hPa, and the level itself on a grid level
+    low = [np.ascontiguousarray(v[:12]) for v in (p, t, td)]
+    assert np.nanmin(low[0]) > 500.0
+    assert np.all(np.isnan(xa.cape_cin_columns(*low, moist=moist, lifted_index_at=500.0)['lifted_index']))
+    p2 = p.copy(); k500 = np.argmin(np.abs(p2 - 500.0), axis=0); p2[k500, np.arange(p2.shape[1])] = 500.0
+    full = xa.cape_cin_columns(p2, t, td, moist=moist, want_profile=True)
+    got = xa.cape_cin_columns(p2, t, td, moist=moist, lifted_index_at=500.0)['lifted_index']
+    ref = xa.lifted_index(full['profile'])
+    ok = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.max(np.abs(got[ok] - ref[ok])) <= 1e-9
+
+
 def test_explicit_parcel_and_ragged_shapes():
     # ncol not a multiple of the wavefront / block, 1 column, 1 level
     for nlev, ncol in ((30, 1), (30, 63), (30, 257), (2, 100), (1, 70)):

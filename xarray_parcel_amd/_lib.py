@@ -59,7 +59,7 @@ PROFILE_VARS = ('pressure', 'temperature', 'virtual_temperature', 'environment_t
 class ProfileOut(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in PROFILE_VARS] +
                 [('dtype', C.c_int32), ('mem', C.c_int32), ('nlev_out', C.c_int64), ('lev_stride', C.c_int64),
-                 ('col_stride', C.c_int64)])
+                 ('col_stride', C.c_int64), ('lifted_index', C.c_void_p), ('lifted_index_pressure', C.c_double)])
 
 
 class Tables(C.Structure):

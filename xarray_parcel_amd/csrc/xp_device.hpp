@@ -620,12 +620,12 @@ struct Family {
 #ifndef XP_CAPE_THREADS
 #define XP_CAPE_THREADS 256
 #endif
-constexpr int SLOT_STRIDE = XP_CAPE_THREADS, SLOT_FIELDS = 12;
+constexpr int SLOT_STRIDE = XP_CAPE_THREADS, SLOT_FIELDS = XP_CAPE_THREADS >= 1024 ? 12 : 13;   // (the 1024-thread family workgroups have no LDS left for SL_LI)
 // SL_A0..A3 are used twice: below the LCL they hold the lower bracket of the LCL interpolation (kernel side:
 // pressure, ln p, T, Td of the last valid level), from the LCL node on the bottom-LFC record -- an LFC has to lie
 // above the LCL (pf.py:1127-1132), so the two never coexist; the LCL node re-initialises them.
 enum { SL_CAPE_LCL = 0, SL_CIN_LCL, SL_MIN_P, SL_IDX /* two int32: lfc index, el index */, SL_LCL_T,
-       SL_A0, SL_A1, SL_A2, SL_A3, SL_EL_X, SL_EL_T, SL_CAPE_EL,
+       SL_A0, SL_A1, SL_A2, SL_A3, SL_EL_X, SL_EL_T, SL_CAPE_EL, SL_LI /* profile kernels: lifted-index state */,
        SL_BR_P = SL_A0, SL_BR_X = SL_A1, SL_BR_T = SL_A2, SL_BR_TD = SL_A3,
        SL_LFC_X = SL_A0, SL_LFC_T = SL_A1, SL_CAPE_LFC = SL_A2, SL_CIN_LFC = SL_A3 };
 
@@ -651,7 +651,7 @@ struct Scan {
         Xp = yp = parp = qnan(); j = 0; use_all = true;
         cape = cin = 0.0;
         for (int f = 0; f < SLOT_FIELDS; ++f)
-            slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T || f == SL_LFC_X || f == SL_EL_X || f == SL_MIN_P) ? qnan() : 0.0;
+            slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T || f == SL_LFC_X || f == SL_EL_X || f == SL_MIN_P || f == SL_LI) ? qnan() : 0.0;
         idx()[0] = -1; idx()[1] = -1;
         any_inc = pos_parcel = env_any = top_le = any_valid = bad_p = false;
     }

@@ -27,9 +27,11 @@ struct ScalarsOut {
     int f64;
 };
 struct ProfileOut {
-    void *v[6];            // p, t_parcel, tv_parcel, t_env, tv_env, td_env
+    void *v[6];            // p, t_parcel, tv_parcel, t_env, tv_env, td_env (each may be null)
     int64_t nlev_out, ls, cs;
     int f64;
+    void *li;              // lifted index (pf.py:1722): environment minus parcel temperature of this profile at exp(li_x) hPa
+    double li_x;           // ln of that pressure
 };
 struct CapeArgs {
     View p, t, td;
@@ -276,9 +278,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
 
     if (isnan_(l.p)) {
         // NaN parcel / LCL blanks the whole profile (pf.py:965-985): CAPE = CIN = 0.0, everything else NaN
-        if (PROFILE)
+        if (PROFILE) {
             for (int64_t j = 0; j < a.prof.nlev_out; ++j)
                 for (int v = 0; v < 6; ++v) st(a.prof.v[v], a.prof.f64, j * a.prof.ls + c * a.prof.cs, qnan());
+            st(a.prof.li, a.prof.f64, c, qnan());
+        }
         st(s.cape, s.f64, c, 0.0); st(s.cin, s.f64, c, 0.0);
         st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
         st(s.lfc_p, s.f64, c, qnan()); st(s.lfc_t, s.f64, c, qnan()); st(s.el_p, s.f64, c, qnan()); st(s.el_t, s.f64, c, qnan());
@@ -309,6 +313,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
 
     int jout = 0;                                                           // profile row
+    double li_d = qnan();                                                   // PROFILE: environment minus parcel temperature of the node before this one (lifted index)
+    bool li_done = false;
     int last_k = -1, cur_k = -1;                                            // LEAN: level index of the last valid-pressure node / of the node being fed
     // `above` (a std::integral_constant): this node and the one before it lie strictly above the LCL (phase B)
     auto emit = [&](auto above, double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
@@ -324,6 +330,25 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
                 st(a.prof.v[5], a.prof.f64, o, dead ? P : tde);
             }
             ++jout;
+            // lifted_index (pf.py:1722 = log_interp of the profile's two temperatures at one pressure, pf.py:1813): the
+            // nodes come with decreasing pressure, so the first one at or above the level closes the bracket that the
+            // node before it opened (coords_before / coords_after of pf.py:1774-1775; a NaN-pressure row is no
+            // coordinate; value rule of pf.py:1802-1806)
+            // -- both temperatures take the same weight, so their difference is interpolated: one value of state.
+            // The state lives in an LDS slot where the workgroup has one to spare (not the 1024-thread family build).
+            if (a.prof.li) {
+                constexpr bool LI_SLOT = SLOT_FIELDS > SL_LI;
+                const double d_ = te - tp;
+                if (!li_done && X <= a.prof.li_x + 1e-12) {
+                    // a node ON the level (the table logarithm and the host's differ in the last bits) is its own bracket
+                    const bool on = X >= a.prof.li_x - 1e-12;
+                    const double dp = LI_SLOT ? sc.slot[(LI_SLOT ? SL_LI : 0) * SLOT_STRIDE] : li_d;
+                    const double wgt = (a.prof.li_x - sc.Xp) / (X - sc.Xp);
+                    st(a.prof.li, a.prof.f64, c, (on || dp == d_) ? d_ : dp + (d_ - dp) * wgt);
+                    li_done = true;
+                }
+                if (!isnan_(P)) { if (LI_SLOT) sc.slot[(LI_SLOT ? SL_LI : 0) * SLOT_STRIDE] = d_; else li_d = d_; }
+            }
         }
         if (LEAN) {      // the lowest valid pressure = the last valid node: remember which level it was instead of storing P
             if (!isnan_(P)) { last_k = (is_lcl || cur_k < 0) ? -1 : cur_k; if (is_lcl || cur_k < 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = P; }
@@ -527,6 +552,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             int64_t o = jout * a.prof.ls + c * a.prof.cs;
             for (int v = 0; v < 6; ++v) st(a.prof.v[v], a.prof.f64, o, qnan());
         }
+        if (!li_done) st(a.prof.li, a.prof.f64, c, qnan());              // the profile never reaches the level
     }
 
     // The output pointers are fetched from the kernel arguments only now, through a pointer the compiler cannot see

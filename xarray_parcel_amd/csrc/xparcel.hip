@@ -481,6 +481,11 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
             if ((rc = st.out(src[v], b, profile->mem, &a.prof.v[v]))) return rc;
         a.prof.nlev_out = profile->nlev_out; a.prof.ls = profile->lev_stride; a.prof.cs = profile->col_stride;
         a.prof.f64 = profile->dtype == XP_F64;
+        if (profile->lifted_index) {
+            if (!(profile->lifted_index_pressure > 0.0)) return fail(XP_E_ARG, "profile: lifted_index_pressure must be positive");
+            if ((rc = st.out(profile->lifted_index, (size_t)a.ncol * esize(profile->dtype), profile->mem, &a.prof.li))) return rc;
+            a.prof.li_x = log(profile->lifted_index_pressure);
+        }
     }
     void *flags = nullptr;
     if (o && o->moist_mode == XP_MOIST_FAMILY && a.ncol > 0) {

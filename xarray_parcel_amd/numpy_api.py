@@ -158,10 +158,12 @@ def set_moist_lapse(mode):
 
 
 def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=None, parcel_values=None,
-                     want_profile=False, want=None, moist=None, **kwargs):
+                     want_profile=False, want=None, moist=None, lifted_index_at=None, **kwargs):
     """pf.py:1394-1475 with the three drivers.  Returns a dict of per-column arrays (and 'profile').
     want_profile: True for the six profile arrays of pf.py:806-931, or an iterable of their names for a subset (the ones
     not named are neither allocated nor written: lifted_index needs three of the six).
+    lifted_index_at: a pressure [hPa] (the reference: 500): 'lifted_index' (pf.py:1722) of the lifted profile comes back
+    with the scalars, computed in the same pass -- no profile array has to exist for it.
     humidity='specific' (keyword): `dewpoint` holds specific humidity [kg/kg] and is converted on load
     (parcel_test.py:262-266 fused into the pass)."""
     (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
@@ -187,11 +189,15 @@ def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=No
         setattr(so, k, ptr)
         out[k] = arr
     po = None
-    if want_profile:
+    if want_profile or lifted_index_at is not None:
         po = L.ProfileOut()
         po.dtype, po.mem, po.nlev_out, po.lev_stride, po.col_stride = p.xp_dtype, p.mem, nlev + 1, ncol, 1
         prof = {}
-        pvars = L.PROFILE_VARS if want_profile is True else tuple(want_profile)
+        if lifted_index_at is not None:
+            arr, ptr = _alloc((ncol,), dt, dev, p)
+            po.lifted_index, po.lifted_index_pressure = ptr, float(lifted_index_at)
+            out['lifted_index'] = arr
+        pvars = L.PROFILE_VARS if want_profile is True else tuple(want_profile or ())
         assert all(k in L.PROFILE_VARS for k in pvars), f'profile variables are {L.PROFILE_VARS}'
         for k in pvars:
             arr, ptr = _alloc((nlev + 1, ncol), dt, dev, p)
@@ -578,17 +584,18 @@ def conv_properties(dat, ignore_nans=False):
     p, t, q, z = to(p), to(t), to(q), to(dat['height_asl'])
     valid = ~(xp.isnan(td).any(0) | xp.isnan(p).any(0) | xp.isnan(t).any(0) | xp.isnan(q).any(0))
     out = {}
-    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, want_profile=LIFTED_INDEX_VARS)
+    # (lifted_index_at: pf.py:1722 on the lifted profile, in the same pass, instead of writing the profile and interpolating it)
+    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, lifted_index_at=500.0)
     out['mu_cape'], out['mu_cin'] = mu['cape'], mu['cin']
     e = 6.112 * xp.exp(17.67 * (mu['parcel_dewpoint'] - 273.15) / (mu['parcel_dewpoint'] - 29.65))
     w = L_EPS * e / (mu['parcel_pressure'] - e)                       # specific_humidity_from_dewpoint -> mixing ratio
     qs = w / (1.0 + w)
     out['mu_mixing_ratio'] = qs / (1.0 - qs)
-    out['mu_lifted_index'] = lifted_index(mu['profile'])
+    out['mu_lifted_index'] = mu['lifted_index']
     for depth in (100, 50):
-        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, want_profile=LIFTED_INDEX_VARS)
+        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, lifted_index_at=500.0)
         out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
-        out[f'mixed_{depth}_lifted_index'] = lifted_index(ml['profile'])
+        out[f'mixed_{depth}_lifted_index'] = ml['lifted_index']
     t850 = interp_level(p, t, 850.0, log=True) - 273.15                # pf.py:1830, the part of the DCI the three share
     td850 = interp_level(p, td, 850.0, log=True) - 273.15
     for pre in ('mu', 'mixed_100', 'mixed_50'):
@@ -619,8 +626,8 @@ def min_conv_properties(dat):
         dat = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).cuda() for k, v in dat.items()}
     p, t, z = dat['pressure'], dat['temperature'], dat['height_asl']
     td = dewpoint_from_specific_humidity(p, t, dat['specific_humidity'])
-    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, want_profile=LIFTED_INDEX_VARS)
-    out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': lifted_index(ml['profile']),
+    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, lifted_index_at=500.0)
+    out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': ml['lifted_index'],
            'lapse_rate_700_500': lapse_rate(p, t, z), 'temp_500': isobar_temperature(p, t, 500.0),
            'freezing_level': freezing_level_height(t, z), 'melting_level': melting_level_height(p, t, td, z)[0]}
     out.update(wind_shear(dat['surface_wind_u'], dat['surface_wind_v'], dat['wind_u'], dat['wind_v'],
