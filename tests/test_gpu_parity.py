@@ -186,6 +186,13 @@ def test_lifted_index_in_the_same_pass(moist):
         assert ok.sum() > 2000 and np.max(np.abs(li[ok] - ref[ok])) <= 1e-9, (parcel, np.max(np.abs(li[ok] - ref[ok])))
         for k in ('cape', 'cin', 'lfc_index', 'el_index'):
             assert np.array_equal(got[k], full[k], equal_nan=True), (parcel, k)
+    # float32 grids: the output takes the grid's type
+    p32, t32, td32 = (v.astype(np.float32) for v in (p, t, td))
+    full = xa.cape_cin_columns(p32, t32, td32, moist=moist, want_profile=True)
+    got = xa.cape_cin_columns(p32, t32, td32, moist=moist, lifted_index_at=500.0)['lifted_index']
+    ref = xa.lifted_index(full['profile'])
+    ok = ~np.isnan(ref)
+    assert got.dtype == np.float32 and np.array_equal(np.isnan(got), np.isnan(ref)) and np.max(np.abs(got[ok] - ref[ok])) <= 2e-4
     # a grid that stops below 500 hPa, and the level itself on a grid level
     low = [np.ascontiguousarray(v[:12]) for v in (p, t, td)]
     assert np.nanmin(low[0]) > 500.0
