@@ -243,6 +243,12 @@ int xp_wet_bulb_temperature(const xp_view *pressure, const xp_view *temperature,
    Used by lifted_index (pf.py:1722), deep_convective_index (pf.py:1830), isobar_temperature (pf.py:2193). */
 int xp_interp_level(const xp_view *coords, const xp_view *variable, const void *at, int32_t at_is_scalar,
                     int32_t log_coords, void *out, void *stream);
+/* The same rule for nvar (1..4) variables at ntarget (1..4) coordinates in one pass over the column: what conv_properties
+   (pf.py:1951) needs of deep_convective_index (pf.py:1830: T, Td at 850 hPa), lapse_rate (pf.py:2102: T, z at 700 and 500)
+   and isobar_temperature (pf.py:2193: T at 500) is one call instead of seven.  out[v * ntarget + j] (ncol values each,
+   NULL = not wanted) = variable v at coordinate at[j]. */
+int xp_interp_levels(const xp_view *coords, int32_t nvar, const xp_view *const *variables, int32_t ntarget, const double *at,
+                     int32_t log_coords, void *const *out, void *stream);
 
 /* metpy.calc.dewpoint_from_specific_humidity in its MetPy 1.4.1 form, the front step of the reference's harness and
    products (parcel_test.py:262-266, pf.py:1889-1894, 1969-1974): w = q/(1-q), RH = w / w_s(p, T),

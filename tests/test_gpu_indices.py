@@ -179,6 +179,25 @@ def test_xarray_mirrors_and_harness(xa):
     assert list(bench['xr_load'].coords['pts']) == [4, 16, 81] and np.all(bench['device'].values > 0)
 
 
+def test_interp_levels_equals_interp_level(xa):
+    """xp_interp_levels: several variables at several coordinates in one pass = xp_interp_level one at a time, bit for bit
+    (NaN levels, duplicate coordinates, coordinates outside the column included)."""
+    p, t, td = synth.columns(nlev=30, ncol=777, seed=61, nan_fraction=0.1, dtype=np.float64)
+    z = _heights(p)
+    p2 = p.copy(); p2[7] = p2[6]                                           # a duplicated coordinate
+    for dtype in (np.float64, np.float32):
+        for log in (True, False):
+            cds = p2.astype(dtype)
+            xs = [t.astype(dtype), td.astype(dtype), z.astype(dtype)]
+            ats = [850.0, 700.0, 500.0, 30.0]
+            got = xa.interp_levels(cds, xs, ats, log=log)
+            for v, x in enumerate(xs):
+                for j, at in enumerate(ats):
+                    assert np.array_equal(got[v][j], xa.interp_level(cds, x, at, log=log), equal_nan=True), (dtype, log, v, at)
+    one = xa.interp_levels(p, [t], [500.0], log=True)
+    assert np.array_equal(one[0][0], xa.isobar_temperature(p, t, 500.0), equal_nan=True)
+
+
 def _bundle_inputs(nlev=40, ncol=48, seed=51, nan_fraction=0.06):
     p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed, nan_fraction=nan_fraction, dtype=np.float64)
     q = _specific_humidity(p, td)

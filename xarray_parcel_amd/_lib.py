@@ -21,7 +21,7 @@ ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 # every symbol include/xparcel.h declares
 SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
-           'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_dewpoint_from_specific_humidity',
+           'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_interp_levels', 'xp_dewpoint_from_specific_humidity',
            'xp_crossing_level', 'xp_mixing_ratio', 'xp_last_error')
 
 

@@ -826,6 +826,65 @@ void k_interp_level(View cv, View xv, int64_t nlev, int64_t ncol, const void *at
     st(out, sizeof(T) == 8, c, (xb == xa) ? xb : res);                     // pf.py:1802-1806
 }
 
+// The same rule for NV variables at NT coordinates in ONE pass over the column (the product bundle interpolates
+// temperature, dewpoint and height to 850 / 700 / 500 hPa: seven launches of k_interp_level that each re-read the
+// pressure).  Per (variable, coordinate) exactly k_interp_level's arithmetic; out[v * NT + j], null = not wanted.
+struct InterpMany { View x[4]; double at[4]; void *out[16]; };
+template <typename T, int NV, int NT> __global__ __launch_bounds__(256)
+void k_interp_levels(View cv, InterpMany m, int64_t nlev, int64_t ncol, int log_coords) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double at[NT], cb[NT], ca[NT], sb[NV][NT], sa[NV][NT];
+    int nb[NV][NT], na[NV][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        at[j] = log_coords ? log(m.at[j]) : m.at[j];
+        cb[j] = ca[j] = qnan();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { sb[v][j] = sa[v][j] = 0.0; nb[v][j] = na[v][j] = 0; }
+    }
+    for (int64_t k = 0; k < nlev; ++k) {
+        double cc = ld<T>(cv, k, c), x[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) x[v] = ld<T>(m.x[v], k, c);
+        if (log_coords) cc = log(cc);
+        if (isnan_(cc)) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (cc >= at[j]) {
+                if (!(cc >= cb[j])) {
+                    cb[j] = cc;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { sb[v][j] = 0.0; nb[v][j] = 0; }
+                }
+                if (cc == cb[j]) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) if (!isnan_(x[v])) { sb[v][j] += x[v]; ++nb[v][j]; }
+                }
+            }
+            if (cc <= at[j]) {
+                if (!(cc <= ca[j])) {
+                    ca[j] = cc;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { sa[v][j] = 0.0; na[v][j] = 0; }
+                }
+                if (cc == ca[j]) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) if (!isnan_(x[v])) { sa[v][j] += x[v]; ++na[v][j]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            double xb = nb[v][j] ? sb[v][j] / (double)nb[v][j] : qnan(), xa = na[v][j] ? sa[v][j] / (double)na[v][j] : qnan();
+            double res = xb + (xa - xb) * ((at[j] - cb[j]) / (ca[j] - cb[j]));
+            st(m.out[v * NT + j], sizeof(T) == 8, c, (xb == xa) ? xb : res);
+        }
+}
+
 // dewpoint_from_specific_humidity (MetPy 1.4.1, parcel_test.py:262-266): one thread per element
 template <typename T> __global__ __launch_bounds__(256)
 void k_dewpoint_from_q(View pv, View tv, View qv, int64_t nlev, int64_t ncol, OutView out) {

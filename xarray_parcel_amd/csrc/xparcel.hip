@@ -371,6 +371,26 @@ int fill_common(Stager &st, const xp_view *p, const xp_view *t, const xp_view *t
 
 }  // namespace
 
+namespace {
+template <typename T, int NV> void launch_interp_levels(int nt, const xp::View &cv, const xp::InterpMany &m, int64_t nlev, int64_t ncol, int lg, hipStream_t s) {
+    dim3 gr(blocks(ncol)), bl(256);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((xp::k_interp_levels<T, NV, 1>), gr, bl, 0, s, cv, m, nlev, ncol, lg); break;
+        case 2: hipLaunchKernelGGL((xp::k_interp_levels<T, NV, 2>), gr, bl, 0, s, cv, m, nlev, ncol, lg); break;
+        case 3: hipLaunchKernelGGL((xp::k_interp_levels<T, NV, 3>), gr, bl, 0, s, cv, m, nlev, ncol, lg); break;
+        default: hipLaunchKernelGGL((xp::k_interp_levels<T, NV, 4>), gr, bl, 0, s, cv, m, nlev, ncol, lg); break;
+    }
+}
+template <typename T> void launch_interp_levels_v(int nv, int nt, const xp::View &cv, const xp::InterpMany &m, int64_t nlev, int64_t ncol, int lg, hipStream_t s) {
+    switch (nv) {
+        case 1: launch_interp_levels<T, 1>(nt, cv, m, nlev, ncol, lg, s); break;
+        case 2: launch_interp_levels<T, 2>(nt, cv, m, nlev, ncol, lg, s); break;
+        case 3: launch_interp_levels<T, 3>(nt, cv, m, nlev, ncol, lg, s); break;
+        default: launch_interp_levels<T, 4>(nt, cv, m, nlev, ncol, lg, s); break;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int xp_version(void) { return XP_VERSION; }
@@ -730,6 +750,34 @@ int xp_interp_level(const xp_view *coords, const xp_view *x, const void *at, int
     if (coords->ncol) {
         if (coords->dtype == XP_F64) hipLaunchKernelGGL((xp::k_interp_level<double>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
         else hipLaunchKernelGGL((xp::k_interp_level<float>), dim3(blocks(coords->ncol)), dim3(256), 0, st.s, cv, xv, coords->nlev, coords->ncol, da, (int)at_is_scalar, (int)log_coords, od);
+    }
+    return st.finish();
+}
+
+int xp_interp_levels(const xp_view *coords, int32_t nvar, const xp_view *const *variables, int32_t ntarget, const double *at,
+                     int32_t log_coords, void *const *out, void *stream) {
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (nvar < 1 || nvar > 4 || ntarget < 1 || ntarget > 4) return fail(XP_E_ARG, "xp_interp_levels: 1..4 variables and 1..4 coordinates");
+    if (!variables || !at || !out) return fail(XP_E_ARG, "xp_interp_levels: null argument");
+    if ((rc = check_view(coords, "coords"))) return rc;
+    Stager st(stream);
+    xp::View cv;
+    xp::InterpMany m;
+    memset(&m, 0, sizeof(m));
+    if ((rc = stage_view(st, coords, &cv))) return rc;
+    size_t cb = (size_t)coords->ncol * esize(coords->dtype);
+    for (int v = 0; v < nvar; ++v) {
+        if ((rc = check_view(variables[v], "variable")) || (rc = same_shape(coords, variables[v], "coords/variable")) ||
+            (rc = stage_view(st, variables[v], &m.x[v]))) return rc;
+        for (int j = 0; j < ntarget; ++j)
+            if ((rc = st.out(out[v * ntarget + j], cb, coords->mem, &m.out[v * ntarget + j]))) return rc;
+    }
+    for (int j = 0; j < ntarget; ++j) m.at[j] = at[j];
+    if (coords->ncol) {
+        if (coords->dtype == XP_F64) launch_interp_levels_v<double>(nvar, ntarget, cv, m, coords->nlev, coords->ncol, (int)log_coords, st.s);
+        else launch_interp_levels_v<float>(nvar, ntarget, cv, m, coords->nlev, coords->ncol, (int)log_coords, st.s);
     }
     return st.finish();
 }

@@ -434,6 +434,25 @@ def interp_level(coords, variable, at, log=False):
     return out.reshape(hshape)
 
 
+def interp_levels(coords, variables, ats, log=False):
+    """interp_level() for up to four variables at up to four scalar coordinates in one pass over the column
+    (xp_interp_levels): returns [[variable v at ats[j] for j] for v]."""
+    arrs, dt, dev = _common(coords, *variables)
+    cds, xs = arrs[0], arrs[1:]
+    assert 1 <= len(xs) <= 4 and 1 <= len(ats) <= 4, 'one to four variables, one to four coordinates'
+    assert all(x.shape == cds.shape for x in xs), 'coords and variables must share a shape'
+    nlev, ncol, hshape = _vert_shape(cds)
+    lib = L.init(_device_of(cds))
+    views = [_view(x, nlev, ncol) for x in xs]
+    vptrs = (C.POINTER(L.View) * len(xs))(*[C.pointer(v) for v in views])
+    outs = [[_alloc((ncol,), dt, dev, cds) for _ in ats] for _ in xs]
+    optrs = (C.c_void_p * (len(xs) * len(ats)))(*[o[1] for row in outs for o in row])
+    at = (C.c_double * len(ats))(*[float(a) for a in ats])
+    L.check(lib.xp_interp_levels(C.byref(_view(cds, nlev, ncol)), C.c_int32(len(xs)), vptrs, C.c_int32(len(ats)), at,
+                                 C.c_int32(int(log)), optrs, _stream(dev)))
+    return [[o[0].reshape(hshape) for o in row] for row in outs]
+
+
 def dewpoint_from_specific_humidity(pressure, temperature, specific_humidity):
     """metpy.calc.dewpoint_from_specific_humidity, MetPy 1.4.1 chain (parcel_test.py:262-266, pf.py:1889), K."""
     (p, t, q), dt, dev = _common(pressure, temperature, specific_humidity)
@@ -596,12 +615,13 @@ def conv_properties(dat, ignore_nans=False):
         ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, lifted_index_at=500.0)
         out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
         out[f'mixed_{depth}_lifted_index'] = ml['lifted_index']
-    t850 = interp_level(p, t, 850.0, log=True) - 273.15                # pf.py:1830, the part of the DCI the three share
-    td850 = interp_level(p, td, 850.0, log=True) - 273.15
+    # temperature, dewpoint and height at 850 / 700 / 500 hPa in ONE pass over the column: what deep_convective_index
+    # (pf.py:1830), lapse_rate (pf.py:2102) and isobar_temperature (pf.py:2193) interpolate one launch at a time
+    (t850, t700, t500), (td850, _, _), (_, z700, z500) = interp_levels(p, [t, td, z], [850.0, 700.0, 500.0], log=True)
     for pre in ('mu', 'mixed_100', 'mixed_50'):
-        out[pre + '_dci'] = t850 + td850 - out[pre + '_lifted_index']
-    out['lapse_rate_700_500'] = lapse_rate(p, t, z)
-    out['temp_500'] = isobar_temperature(p, t, 500.0)
+        out[pre + '_dci'] = (t850 - 273.15) + (td850 - 273.15) - out[pre + '_lifted_index']
+    out['lapse_rate_700_500'] = (t500 - t700) / (z500 / 1000 - z700 / 1000)
+    out['temp_500'] = t500
     out['freezing_level'] = freezing_level_height(t, z)
     out['melting_level'], _ = melting_level_height(p, t, td, z)
     out.update(wind_shear(to(dat['surface_wind_u']), to(dat['surface_wind_v']), to(dat['wind_u']), to(dat['wind_v']),
@@ -627,8 +647,9 @@ def min_conv_properties(dat):
     p, t, z = dat['pressure'], dat['temperature'], dat['height_asl']
     td = dewpoint_from_specific_humidity(p, t, dat['specific_humidity'])
     ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, lifted_index_at=500.0)
+    (t700, t500), (z700, z500) = interp_levels(p, [t, z], [700.0, 500.0], log=True)      # pf.py:2102, 2193 in one pass
     out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': ml['lifted_index'],
-           'lapse_rate_700_500': lapse_rate(p, t, z), 'temp_500': isobar_temperature(p, t, 500.0),
+           'lapse_rate_700_500': (t500 - t700) / (z500 / 1000 - z700 / 1000), 'temp_500': t500,
            'freezing_level': freezing_level_height(t, z), 'melting_level': melting_level_height(p, t, td, z)[0]}
     out.update(wind_shear(dat['surface_wind_u'], dat['surface_wind_v'], dat['wind_u'], dat['wind_v'],
                           dat['wind_height_above_surface']))
