@@ -500,6 +500,9 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
         for (int v = 0; v < 6; ++v)
             if ((rc = st.out(src[v], b, profile->mem, &a.prof.v[v]))) return rc;
         a.prof.nlev_out = profile->nlev_out; a.prof.ls = profile->lev_stride; a.prof.cs = profile->col_stride;
+        bool rows = false;
+        for (int v = 0; v < 6; ++v) rows = rows || a.prof.v[v] != nullptr;
+        if (!rows) a.prof.nlev_out = 0;                    // lifted index only: the kernel's row loops see an empty profile
         a.prof.f64 = profile->dtype == XP_F64;
         if (profile->lifted_index) {
             if (!(profile->lifted_index_pressure > 0.0)) return fail(XP_E_ARG, "profile: lifted_index_pressure must be positive");
