@@ -69,7 +69,9 @@ def virtual_temperature(p, t):
 
 def temperature_of(p, tv, steps=5):
     """The T with virtual_temperature(p, T) = tv: Newton from T0 = tv / (1 + 0.608 w_s(p, tv)), a fixed number of
-    steps (1e-13 K after five wherever e_s <= 0.1 p, i.e. everywhere on the table; 4e-8 K after four)."""
+    steps (1e-13 K after five wherever e_s <= 0.1 p, i.e. everywhere on the table; 4e-8 K after four).  (The device's
+    profile kernels reach the same root from a warm start -- Tv - T of the node before -- in three steps, with a residual
+    test that adds two: same value to 1e-13 K, csrc/xp_device.hpp Family::temperature_from.)"""
     c = th.VT_EPSILON * th.EPSILON
     t = tv / (1.0 + th.VT_EPSILON * th.saturation_mixing_ratio(p, tv))
     for _ in range(steps):

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     Family fam;
     if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t, l.tv);
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
+    double fam_off = l.tv - l.t;                                            // family profile kernels: Tv - T of the parcel at the node before (temperature_from)
 
     int jout = 0;                                                           // profile row
     double li_d = qnan();                                                   // PROFILE: environment minus parcel temperature of the node before this one (lifted index)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         double tp, tvp;
         if (FAMILY) {
             tvp = tf;
-            tp = (PROFILE || !vtc) ? Family::temperature_of(es, P, tf) : tf;   // (not used when neither holds)
+            tp = PROFILE ? Family::temperature_from(es, P, tf, fam_off) : !vtc ? Family::temperature_of(es, P, tf) : tf;   // (not used when neither holds)
         } else {
             tp = tf;
             tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                                // pf.py:760
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             tvp = need_w ? virt(tp, w_parcel) : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
             tvp = fam.at(X);
-            tp = (PROFILE || !vtc) ? Family::temperature_of(es, P, tvp) : tvp;
+            tp = PROFILE ? Family::temperature_from(es, P, tvp, fam_off) : !vtc ? Family::temperature_of(es, P, tvp) : tvp;
         } else {
             tp = m.at(P, X, a.tb);
             tvp = need_w ? virt(tp, mix_of_e(TABLE ? es_tab(es, tp) : m.e, P)) : tp;
