@@ -254,7 +254,8 @@ def test_truncated_columns_lcl_at_and_above_the_top(moist):
                 assert not ok.any() or np.max(np.abs(a[ok] - b[ok])) <= 1e-8, (nlev, parcel, k)
 
 
-def test_nan_pressure_levels():
+@pytest.mark.parametrize('moist', ['exact', 'family'])
+def test_nan_pressure_levels(moist):
     """A NaN PRESSURE inside a column (outside the reference's input contract, README.md:9).
     Above the LCL the kernel follows the reference (the level is an all-NaN node).  Below the LCL the reference's
     insert_level puts a copy of the LCL into the NaN slot (its fill-value trick, pf.py:962-966) and integrates over the
@@ -264,7 +265,8 @@ def test_nan_pressure_levels():
     the contract."""
     nlev, ncol = 30, 4000
     p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=9, dtype=np.float64)
-    base = co.cape_cin_grid(p, t, td, moist='rk4')
+    omode = ('rk4' if moist == 'exact' else 'family')
+    base = co.cape_cin_grid(p, t, td, moist=omode)
     first_above = np.argmax(p < base['lcl_pressure'][None, :], axis=0)         # first level above the LCL
     q, t2, td2 = p.copy(), t.copy(), td.copy()
     kind = np.arange(ncol) % 3
@@ -275,15 +277,15 @@ def test_nan_pressure_levels():
     q[kb, below] = np.nan
     q[ka, above] = np.nan
     t2[kb, below] = np.nan; td2[kb, below] = np.nan                            # the "missing level" reading of the same columns
-    got = xa.cape_cin_columns(q, t, td)
+    got = xa.cape_cin_columns(q, t, td, moist=moist)
     st = np.asarray(got['status'])
     assert np.all(st[below] & 4) and not np.any(st[above] & 4) and not np.any(st[kind == 2] & 4)
     # above the LCL, and untouched columns: the reference's semantics
-    ref = co.cape_cin_grid(q, t, td, moist='rk4')
+    ref = co.cape_cin_grid(q, t, td, moist=omode)
     sel = kind != 0
     _compare({k: np.asarray(v)[sel] for k, v in got.items()}, {k: v[sel] for k, v in ref.items()}, np.float64, 1e-6)
     # below the LCL: a missing level
-    miss = co.cape_cin_grid(p, t2, td2, moist='rk4')
+    miss = co.cape_cin_grid(p, t2, td2, moist=omode)
     g = {k: np.asarray(v)[below] for k, v in got.items()}
     g['status'] = g['status'] & ~4
     _compare(g, {k: v[below] for k, v in miss.items()}, np.float64, 1e-6)
