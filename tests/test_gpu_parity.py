@@ -214,13 +214,14 @@ def test_lifted_index_in_the_same_pass(moist):
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.max(np.abs(got[ok] - ref[ok])) <= 1e-9
 
 
-def test_explicit_parcel_and_ragged_shapes():
-    # ncol not a multiple of the wavefront / block, 1 column, 1 level
-    for nlev, ncol in ((30, 1), (30, 63), (30, 257), (2, 100), (1, 70)):
+@pytest.mark.parametrize('moist', ['exact', 'family'])
+def test_explicit_parcel_and_ragged_shapes(moist):
+    # ncol not a multiple of the wavefront / block (1024 columns per workgroup in family mode), 1 column, 1 level
+    for nlev, ncol in ((30, 1), (30, 63), (30, 257), (30, 1025), (2, 100), (1, 70)):
         p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=3, nan_fraction=0.05, dtype=np.float64)
         pv = np.stack([p[0] + 5.0, t[0] + 1.0, td[0] - 1.0])
-        got = xa.cape_cin_columns(p, t, td, parcel='explicit', parcel_values=(pv[0], pv[1], pv[2]))
-        ref = co.cape_cin_grid(p, t, td, parcel='explicit', parcel_values=pv, moist='rk4')
+        got = xa.cape_cin_columns(p, t, td, parcel='explicit', parcel_values=(pv[0], pv[1], pv[2]), moist=moist)
+        ref = co.cape_cin_grid(p, t, td, parcel='explicit', parcel_values=pv, moist='rk4' if moist == 'exact' else 'family')
         _compare(got, ref, np.float64, 1e-6)
     # empty grid
     e = np.empty((10, 0))
