@@ -27,6 +27,16 @@ for ncol in (1, 63, 4097, 70001):
             tp._compare(got, ref, dtype, 1e-6)
             lean = xa.cape_cin_columns(p, t, td, parcel=parcel, moist='family', want=('cape', 'cin'))
             assert np.array_equal(lean['cape'], got['cape'], equal_nan=True)
+# specific-humidity input (the HUM instantiations) under persistence
+from oracle import thermo as th
+p, t, td = synth.columns(nlev=33, ncol=5000, seed=5, nan_fraction=0.08, dtype=np.float64)
+e = th.saturation_vapor_pressure(td); w = th.EPSILON * e / (p - e); q = w / (1.0 + w)
+with np.errstate(all='ignore'):
+    td_ref = th.dewpoint_from_specific_humidity(p, t, q)
+for parcel in ('surface', 'mixed_layer'):
+    got = xa.cape_cin_columns(p, t, q, parcel=parcel, moist='family', humidity='specific')
+    ref = co.cape_cin_grid(p, t, td_ref, parcel=parcel, moist='family')
+    tp._compare(got, ref, np.float64, 1e-6)
 print('PERSISTENT_OK')
 ''' % ROOT
 
