@@ -21,3 +21,15 @@ def _native_builds():
     from oracle import c_oracle
     c_oracle.build()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _kat_moist_mode():
+    """The reference runs its known-answer tests with parcel.moist_lapse replaced by MetPy's ODE
+    (parcel_functions_demo.ipynb cell 33, unit_tests.py:114-140); the mirror's counterpart is set_moist_lapse('exact').
+    Tests of the mirror's DEFAULT behaviour (lookup tables, as in the reference) switch it back with
+    set_moist_lapse(None)."""
+    from xarray_parcel_amd import parcel_functions as pf
+    pf.set_moist_lapse('exact')
+    yield
+    pf.set_moist_lapse('exact')

@@ -58,7 +58,7 @@ def _saturated_tie_columns(got, ref):
       (b) the SIGN of that difference, i.e. whether a crossing is seen on the LCL at all: a different LFC altogether.
           Both outcomes are "the reference's result".  Measured: about 4 % of SATURATED columns (device-library vs glibc
           exp/log differ in the last bit for that fraction of inputs); the synthetic correctness grids hold 3 % saturated
-          columns, so such columns must stay below 0.25 % of the grid, and they are left out of the comparison.
+          columns, so such columns must stay below 0.125 % of the grid (label ties: 0.5 %), and they are left out of the comparison.
     Everything else must agree exactly.  Returns (label_only, excluded) boolean masks."""
     lcl = ref['lcl_pressure']
     lcl_on_parcel = lcl == np.asarray(got['parcel_pressure'], dtype=np.float64)
@@ -77,8 +77,9 @@ def _saturated_tie_columns(got, ref):
                      (np.abs(ref['el_pressure'] - lcl) <= 1e-9 * lcl))
     el_tie = lcl_on_parcel & (ge != re_) & el_on_lcl
     excluded = (tie & ~label_only) | el_tie
-    assert excluded.sum() <= max(2, tie.size // 400), ('too many saturated-parcel sign ties', int(excluded.sum()))
-    assert label_only.sum() <= max(4, tie.size // 100), ('too many LCL-label ties', int(label_only.sum()))
+    # measured rate of either class: ~0.12 % of a grid with 3 % saturated columns (round-2 soak)
+    assert excluded.sum() <= max(2, tie.size // 800), ('too many saturated-parcel sign ties', int(excluded.sum()))
+    assert label_only.sum() <= max(4, tie.size // 200), ('too many LCL-label ties', int(label_only.sum()))
     return label_only, excluded
 
 
@@ -339,15 +340,19 @@ def test_errors_are_loud():
     assert 'CODE -3' in out.stdout and 'load_moist_adiabat_lookups' in out.stdout, (out.stdout, out.stderr[-500:])
 
 
-def test_full_size_properties_config2():
+@pytest.mark.parametrize('moist,want', [('exact', ('cape', 'cin', 'lfc_index', 'el_index', 'lfc_pressure', 'el_pressure')),
+                                        ('family', ('cape', 'cin'))])
+def test_full_size_properties_config2(moist, want):
     """BASELINE config c2 (64 x 1024 x 1024 fp64): determinism, column-permutation equivariance, shard
-    invariance, sign constraints, and a strided sample against the oracle."""
+    invariance, sign constraints, and a strided sample against the oracle -- for the RK4 kernel with the LFC / EL
+    outputs, and for exactly the call bench.py times (family mode, CAPE / CIN only: the benched instantiation at the
+    benched shape)."""
     import torch
     nlev, ncol = 64, 1024 * 1024
     p, t, td = synth.columns_torch(nlev, ncol, 'cuda', seed=20250719, dtype=torch.float64)
-    want = ('cape', 'cin', 'lfc_index', 'el_index', 'lfc_pressure', 'el_pressure')
-    a = xa.cape_cin_columns(p, t, td, want=want)
-    b = xa.cape_cin_columns(p, t, td, want=want)
+    exact_keys = tuple(k for k in ('cape', 'cin', 'lfc_index', 'el_index') if k in want)
+    a = xa.cape_cin_columns(p, t, td, want=want, moist=moist)
+    b = xa.cape_cin_columns(p, t, td, want=want, moist=moist)
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(a[k], b[k]) or torch.equal(torch.isnan(a[k]), torch.isnan(b[k])), k
@@ -355,19 +360,21 @@ def test_full_size_properties_config2():
     assert float(a['cape'].max()) > 100.0                                     # the workload is not trivial
     # shard invariance: the second half computed alone equals the second half of the whole
     h = ncol // 2
-    s = xa.cape_cin_columns(p[:, h:].contiguous(), t[:, h:].contiguous(), td[:, h:].contiguous(), want=want)
-    for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+    s = xa.cape_cin_columns(p[:, h:].contiguous(), t[:, h:].contiguous(), td[:, h:].contiguous(), want=want, moist=moist)
+    for k in exact_keys:
         assert torch.equal(s[k], a[k][h:]), k
     # permutation equivariance
     perm = torch.randperm(ncol, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0))
-    q = xa.cape_cin_columns(p[:, perm].contiguous(), t[:, perm].contiguous(), td[:, perm].contiguous(), want=want)
-    for k in ('cape', 'cin', 'lfc_index', 'el_index'):
+    q = xa.cape_cin_columns(p[:, perm].contiguous(), t[:, perm].contiguous(), td[:, perm].contiguous(), want=want, moist=moist)
+    for k in exact_keys:
         assert torch.equal(q[k], a[k][perm]), k
-    # strided sample against the oracle
+    # strided sample against the oracle (in the same moist mode)
     idx = torch.arange(0, ncol, 257, device='cuda')
-    ref = co.cape_cin_grid(p[:, idx].cpu().numpy(), t[:, idx].cpu().numpy(), td[:, idx].cpu().numpy(), moist='rk4')
+    ref = co.cape_cin_grid(p[:, idx].cpu().numpy(), t[:, idx].cpu().numpy(), td[:, idx].cpu().numpy(),
+                           moist='rk4' if moist == 'exact' else 'family')
     for k in ('lfc_index', 'el_index'):
-        assert np.array_equal(a[k][idx].cpu().numpy(), ref[k]), k
+        if k in want:
+            assert np.array_equal(a[k][idx].cpu().numpy(), ref[k]), k
     for k in ('cape', 'cin'):
         assert np.max(np.abs(a[k][idx].cpu().numpy() - ref[k])) <= 1e-6, k
 

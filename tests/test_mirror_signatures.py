@@ -13,8 +13,10 @@ from xarray_parcel_amd import parcel_test as pt
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_signatures.json')))
 # mirror-only extras that are allowed on top of the reference's arguments (always keyword, always after them)
-EXTRA = {'moist_lapse': {'moist'}, 'surface_cape_vector': {'fused'}, 'melting_level_height': set(), 'benchmark_cape': {'vert_dim'},
-         'dewpoint_from_specific_humidity': set()}
+# (`moist`: per-call choice of the moist adiabat -- None = the reference's lookup tables; see parcel_functions._moist_mode)
+EXTRA = {'moist_lapse': {'moist'}, 'surface_cape_vector': {'fused'}, 'melting_level_height': {'moist'}, 'benchmark_cape': {'vert_dim'},
+         'dewpoint_from_specific_humidity': set(), 'conv_properties': {'moist'}, 'min_conv_properties': {'moist'},
+         'parcel_profile': {'moist'}, 'parcel_profile_with_lcl': {'moist'}, 'wet_bulb_temperature': {'moist'}}
 # deliberately not mirrored: internals of the reference's array implementation that the streaming kernel replaces, its
 # table generator / notebook helpers, and the MetPy / serial comparison legs of the harness
 NOT_MIRRORED_OK = True

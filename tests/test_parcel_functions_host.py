@@ -82,6 +82,64 @@ def test_mu_profile_is_trimmed(stub):
     assert res.cape.attrs['description'] == 'CAPE for most-unstable parcel in lowest 100 hPa.'
 
 
+def test_default_moist_mode_is_the_references(stub, monkeypatch):
+    """pf.py:525-607 + 56-61: an unchanged reference call sequence gets the lookup-table moist lapse, and a moist call
+    before load_moist_adiabat_lookups() raises the reference's assert."""
+    i = kr.inputs('test_surface_based_cape_cin')
+    p, t, td = _da(i['levels']), _da(i['temperatures']), _da(i['dewpoints'])
+    pf.set_moist_lapse(None)                                   # the module as a caller of the reference finds it
+    loaded = {'v': 0}
+
+    class _Lib:
+        def xp_tables_loaded(self):
+            return loaded['v']
+    from xarray_parcel_amd import _lib
+    monkeypatch.setattr(_lib, 'load', lambda: _Lib())
+    for call in (lambda: pf.surface_based_cape_cin(p, t, td),
+                 lambda: pf.moist_lapse(p, np.array([300.0])),
+                 lambda: pf.parcel_profile(p, p[0:1], t[0:1], td[0:1]),
+                 lambda: pf.wet_bulb_temperature(p, t, td),
+                 lambda: pf.parcel_profile_with_lcl(p, t, td, p[0:1], t[0:1], td[0:1])):
+        with pytest.raises(AssertionError, match='Call load_moist_adiabat_lookups first.'):
+            call()
+    seen = {}
+
+    def spy(p_, t_, td_, **kw):
+        seen.update(kw)
+        kw.pop('moist')
+        return _stand_in(p_, t_, td_, **kw)
+    monkeypatch.setattr(pf._api, 'cape_cin_columns', spy)
+    loaded['v'] = 1                                              # load_moist_adiabat_lookups() has run
+    pf.surface_based_cape_cin(p, t, td)
+    assert seen['moist'] == 'table'
+    pf.surface_based_cape_cin(p, t, td, moist='family')          # opt-in per call
+    assert seen['moist'] == 'family'
+    pf.set_moist_lapse('exact')                                  # opt-in per module (what the KAT runs do)
+    pf.surface_based_cape_cin(p, t, td)
+    assert seen['moist'] == 'exact'
+
+
+@pytest.mark.gpu
+def test_default_moist_mode_on_gpu():
+    """The same on the device: before the tables exist the reference's assert, after load_moist_adiabat_lookups() the
+    lookup-table answer (= moist='table', and different from the ODE's by the table's error)."""
+    i = kr.inputs('test_surface_based_cape_cin')
+    p, t, td = _da(i['levels']), _da(i['temperatures']), _da(i['dewpoints'])
+    from xarray_parcel_amd import _lib
+    pf.set_moist_lapse(None)
+    if not _lib.load().xp_tables_loaded():
+        with pytest.raises(AssertionError, match='Call load_moist_adiabat_lookups first.'):
+            pf.surface_based_cape_cin(p, t, td)
+    pf.load_moist_adiabat_lookups(cache=False)
+    res, _ = pf.surface_based_cape_cin(p, t, td)
+    tab, _ = pf.surface_based_cape_cin(p, t, td, moist='table')
+    ode, _ = pf.surface_based_cape_cin(p, t, td, moist='exact')
+    assert float(res.cape.values) == float(tab.cape.values)
+    assert 1e-3 < abs(float(res.cape.values) - float(ode.cape.values)) < 40.0     # demo.ipynb:320-329: up to 33 J/kg
+    ml = pf.moist_lapse(_da([1000., 900., 800.]), np.array([293.0]))
+    assert np.allclose(np.asarray(ml.values).ravel(), [293.0, 288.7, 284.0], atol=0.3)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['test_surface_based_cape_cin', 'test_surface_based_cape_cin_mp',
                                   'test_sensitive_sounding', 'test_cape_cin_value_error'])

@@ -513,6 +513,7 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
     void *flags = nullptr;
     if (o && o->moist_mode == XP_MOIST_FAMILY && a.ncol > 0) {
         HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)a.ncol, st.s));   // stream-ordered scratch: which columns need RK4
+        st.scratch.push_back(flags);                         // released by the Stager on every path out of this function
         a.flags = (int32_t *)flags;
         // large grids run persistent wavefronts (k_cape_cin, PERSIST); XP_PERSIST_MIN_COLS: A/B.  Measured
         // (scripts/run_gpu_persist.py): the searching parcels gain 4-14 % from 1 Mi columns on (uneven work per wavefront),
@@ -524,7 +525,6 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
     }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
     else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
-    if (flags) HIP_TRY(hipFreeAsync(flags, st.s));
     return st.finish();
 }
 

@@ -587,7 +587,7 @@ def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh
     return ship
 
 
-def conv_properties(dat, ignore_nans=False):
+def conv_properties(dat, ignore_nans=False, moist=None):
     """pf.py:1951: the reference's convective-property bundle for a grid.  `dat`: mapping with pressure [hPa],
     temperature [K], specific_humidity [kg/kg], height_asl [m] (nlev, ...), wind_u, wind_v,
     wind_height_above_surface (nwind, ...), surface_wind_u, surface_wind_v (...).  Returns a dict of per-column
@@ -604,7 +604,7 @@ def conv_properties(dat, ignore_nans=False):
     valid = ~(xp.isnan(td).any(0) | xp.isnan(p).any(0) | xp.isnan(t).any(0) | xp.isnan(q).any(0))
     out = {}
     # (lifted_index_at: pf.py:1722 on the lifted profile, in the same pass, instead of writing the profile and interpolating it)
-    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, lifted_index_at=500.0)
+    mu = cape_cin_columns(p, t, td, parcel='most_unstable', depth=250, lifted_index_at=500.0, moist=moist)
     out['mu_cape'], out['mu_cin'] = mu['cape'], mu['cin']
     e = 6.112 * xp.exp(17.67 * (mu['parcel_dewpoint'] - 273.15) / (mu['parcel_dewpoint'] - 29.65))
     w = L_EPS * e / (mu['parcel_pressure'] - e)                       # specific_humidity_from_dewpoint -> mixing ratio
@@ -612,7 +612,7 @@ def conv_properties(dat, ignore_nans=False):
     out['mu_mixing_ratio'] = qs / (1.0 - qs)
     out['mu_lifted_index'] = mu['lifted_index']
     for depth in (100, 50):
-        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, lifted_index_at=500.0)
+        ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=depth, lifted_index_at=500.0, moist=moist)
         out[f'mixed_{depth}_cape'], out[f'mixed_{depth}_cin'] = ml['cape'], ml['cin']
         out[f'mixed_{depth}_lifted_index'] = ml['lifted_index']
     # temperature, dewpoint and height at 850 / 700 / 500 hPa in ONE pass over the column: what deep_convective_index
@@ -637,7 +637,7 @@ def conv_properties(dat, ignore_nans=False):
     return out
 
 
-def min_conv_properties(dat):
+def min_conv_properties(dat, moist=None):
     """pf.py:1873: the minimal bundle -- 100 hPa mixed-layer CAPE / CIN and lifted index, 700-500 hPa lapse rate, 500 hPa
     temperature, freezing and melting level, 0-6 km shear.  Same input mapping as conv_properties(); no NaN blanking
     (the reference has none here)."""
@@ -646,7 +646,7 @@ def min_conv_properties(dat):
         dat = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).cuda() for k, v in dat.items()}
     p, t, z = dat['pressure'], dat['temperature'], dat['height_asl']
     td = dewpoint_from_specific_humidity(p, t, dat['specific_humidity'])
-    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, lifted_index_at=500.0)
+    ml = cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, lifted_index_at=500.0, moist=moist)
     (t700, t500), (z700, z500) = interp_levels(p, [t, z], [700.0, 500.0], log=True)      # pf.py:2102, 2193 in one pass
     out = {'mixed_100_cape': ml['cape'], 'mixed_100_cin': ml['cin'], 'mixed_100_lifted_index': ml['lifted_index'],
            'lapse_rate_700_500': (t500 - t700) / (z500 / 1000 - z700 / 1000), 'temp_500': t500,

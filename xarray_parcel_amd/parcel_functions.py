@@ -82,7 +82,35 @@ def _raise_like_reference(e):
     raise e
 
 
+# -- which moist adiabat a call uses --------------------------------------------------------------------
+# The reference has ONE moist_lapse: the lookup-table one (pf.py:525-607), and every call of it starts with
+# lookup_tables_loaded() (pf.py:554, 56-61).  So here: unless the caller names a mode (`moist=` keyword, an extension
+# of this mirror) or has switched the module default with set_moist_lapse(), every function that lifts a parcel
+# moist-adiabatically uses the tables handed over by load_moist_adiabat_lookups() and raises the reference's
+# 'Call load_moist_adiabat_lookups first.' when there are none.  set_moist_lapse('exact') is the counterpart of what
+# the reference's own known-answer tests do (`parcel.moist_lapse = tests.metpy_moist_lapse`,
+# parcel_functions_demo.ipynb cell 33, unit_tests.py:114-140): MetPy's ODE instead of the tables.
+_MOIST = {'override': None}
+
+
+def set_moist_lapse(mode=None):
+    """Module-wide moist-adiabat mode: None (the reference's behaviour: lookup tables), 'exact' (MetPy's ODE by RK4),
+    'family' (the same ODE from the adiabat-family table) or 'table'."""
+    assert mode is None or mode in _api.L.MOIST, "mode must be None, 'exact', 'family' or 'table'"
+    _MOIST['override'] = mode
+
+
+def _moist_mode(moist=None):
+    if moist is not None:
+        return moist
+    if _MOIST['override'] is not None:
+        return _MOIST['override']
+    lookup_tables_loaded()                                                               # pf.py:554
+    return 'table'
+
+
 def _run(pressure, temperature, dewpoint, vert_dim, parcel, depth=None, parcel_values=None, trim=False, **kwargs):
+    kwargs['moist'] = _moist_mode(kwargs.get('moist'))
     p, dims, coords, vc = _split(pressure, vert_dim)
     t, _, _, _ = _split(temperature, vert_dim)
     td, _, _, _ = _split(dewpoint, vert_dim)
@@ -202,8 +230,9 @@ def dry_lapse(pressure, parcel_temperature, parcel_pressure=None, vert_dim=VERT)
 
 
 def moist_lapse(pressure, parcel_temperature, parcel_pressure=None, vert_dim=VERT, persist=True, moist=None):
-    """pf.py:525.  `moist='table'` (after load_moist_adiabat_lookups) reproduces the reference's lookup;
-    the default is the exact ODE."""
+    """pf.py:525: the reference's table lookup (needs load_moist_adiabat_lookups() first, pf.py:554); `moist='exact'`
+    / `'family'` or set_moist_lapse() select the ODE instead (an extension of this mirror)."""
+    moist = _moist_mode(moist)
     p, dims, coords, vc = _split(pressure, vert_dim)
     pt = np.asarray(getattr(parcel_temperature, 'values', parcel_temperature), dtype=np.float64)
     pp = None if parcel_pressure is None else np.asarray(getattr(parcel_pressure, 'values', parcel_pressure))
@@ -214,12 +243,16 @@ def moist_lapse(pressure, parcel_temperature, parcel_pressure=None, vert_dim=VER
     return _vert(out, vert_dim, vc, dims, coords, attrs={'long_name': 'Moist lapse rate temperature', 'units': 'K'})
 
 
-def parcel_profile(pressure, parcel_pressure, parcel_temperature, parcel_dewpoint, vert_dim=VERT):
+def parcel_profile(pressure, parcel_pressure, parcel_temperature, parcel_dewpoint, vert_dim=VERT, moist=None):
     """pf.py:712."""
+    moist = _moist_mode(moist)
     p, dims, coords, vc = _split(pressure, vert_dim)
     pv = [np.asarray(getattr(x, 'values', x), dtype=np.float64) for x in
           (parcel_pressure, parcel_temperature, parcel_dewpoint)]
-    r = _api.parcel_profile(p, *pv)
+    try:
+        r = _api.parcel_profile(p, *pv, moist=moist)
+    except XParcelError as e:
+        _raise_like_reference(e)
     out = Dataset()
     out['pressure'] = _vert(p, vert_dim, vc, dims, coords, name='pressure')
     out['temperature'] = _vert(_np(r['temperature']), vert_dim, vc, dims, coords,
@@ -232,12 +265,12 @@ def parcel_profile(pressure, parcel_pressure, parcel_temperature, parcel_dewpoin
 
 
 def parcel_profile_with_lcl(pressure, temperature, dewpoint, parcel_pressure, parcel_temperature, parcel_dewpoint,
-                            vert_dim=VERT, lcl_interp='log'):
+                            vert_dim=VERT, lcl_interp='log', moist=None):
     """pf.py:806."""
     pv = tuple(np.asarray(getattr(x, 'values', x), dtype=np.float64)
                for x in (parcel_pressure, parcel_temperature, parcel_dewpoint))
     _, profile, _ = _run(pressure, temperature, dewpoint, vert_dim, 'explicit', parcel_values=pv,
-                         lcl_interp=lcl_interp)
+                         lcl_interp=lcl_interp, moist=moist)
     return Dataset({k: profile[k] for k in _PROFILE_KEYS + _LCL_KEYS})
 
 
@@ -302,12 +335,16 @@ def mixed_layer(dat, depth=100, vert_dim=VERT):
 
 
 # -- SURVEY 8(f) items on the same kernels ------------------------------------------------------------------------
-def wet_bulb_temperature(pressure, temperature, dewpoint, vert_dim=VERT):
-    """pf.py:389."""
+def wet_bulb_temperature(pressure, temperature, dewpoint, vert_dim=VERT, moist=None):
+    """pf.py:389 (Normand's rule; its descent is a moist_lapse call, pf.py:436)."""
+    moist = _moist_mode(moist)
     p, dims, coords, vc = _split(pressure, vert_dim)
     t, _, _, _ = _split(temperature, vert_dim)
     td, _, _, _ = _split(dewpoint, vert_dim)
-    out = _np(_api.wet_bulb_temperature(p, t, td))
+    try:
+        out = _np(_api.wet_bulb_temperature(p, t, td, moist=moist))
+    except XParcelError as e:
+        _raise_like_reference(e)
     if vc is None:
         return _horiz(out.reshape(p.shape), dims, coords, name='wet_bulb_temperature',
                       attrs={'long_name': 'Wet bulb temperature', 'units': 'K'})
@@ -404,12 +441,13 @@ def freezing_level_height(temperature, height, vert_dim=VERT):
                          'description': 'Height of zero degree dry-bulb temperature isotherm.', 'units': 'm'})
 
 
-def melting_level_height(pressure, temperature, dewpoint, height, fast=True, vert_dim=VERT):
+def melting_level_height(pressure, temperature, dewpoint, height, fast=True, vert_dim=VERT, moist=None):
     """pf.py:2160: freezing level of the wet-bulb temperature; returns (melting level, wet bulb)."""
     if fast:
         wb = wet_bulb_temperature_fast(temperature=temperature, dewpoint=dewpoint)
     else:
-        wb = wet_bulb_temperature(pressure=pressure, temperature=temperature, dewpoint=dewpoint, vert_dim=vert_dim)
+        wb = wet_bulb_temperature(pressure=pressure, temperature=temperature, dewpoint=dewpoint, vert_dim=vert_dim,
+                                  moist=moist)
     mlh = freezing_level_height(temperature=wb, height=height, vert_dim=vert_dim)
     mlh.attrs['long_name'] = 'Melting-level height'
     mlh.attrs['description'] = 'Height of zero degree wet-bulb temperature isotherm.'
@@ -485,10 +523,10 @@ _BUNDLE_ATTRS = {
 }
 
 
-def conv_properties(dat, vert_dim=VERT, ignore_nans=False):
+def conv_properties(dat, vert_dim=VERT, ignore_nans=False, moist=None):
     """pf.py:1951: the convective-property bundle.  `dat` holds pressure, temperature, specific_humidity, height_asl on
     `vert_dim`, wind_u, wind_v, wind_height_above_surface on their own vertical, surface_wind_u, surface_wind_v."""
-    return _bundle(dat, vert_dim, _api.conv_properties, ignore_nans=ignore_nans)
+    return _bundle(dat, vert_dim, _api.conv_properties, ignore_nans=ignore_nans, moist=_moist_mode(moist))
 
 
 def _bundle(dat, vert_dim, fn, **kw):
@@ -497,7 +535,10 @@ def _bundle(dat, vert_dim, fn, **kw):
     arrs = {k: _split(dat[k], vert_dim)[0] for k in ('pressure', 'temperature', 'specific_humidity', 'height_asl')}
     arrs.update({k: _split(dat[k], wdim)[0] for k in ('wind_u', 'wind_v', 'wind_height_above_surface')})
     arrs.update({k: _split(dat[k], vert_dim)[0] for k in ('surface_wind_u', 'surface_wind_v')})
-    r = fn(arrs, **kw)
+    try:
+        r = fn(arrs, **kw)
+    except XParcelError as e:
+        _raise_like_reference(e)
     out = Dataset()
     for k, v in r.items():
         attrs = dict(_BUNDLE_ATTRS.get(k, {}))
@@ -512,10 +553,10 @@ def _bundle(dat, vert_dim, fn, **kw):
     return out
 
 
-def min_conv_properties(dat, vert_dim=VERT):
+def min_conv_properties(dat, vert_dim=VERT, moist=None):
     """pf.py:1873: the minimal property set (mixed-layer CAPE/CIN + lifted index, lapse rate, T500, freezing / melting
     level, 0-6 km shear)."""
-    return _bundle(dat, vert_dim, _api.min_conv_properties)
+    return _bundle(dat, vert_dim, _api.min_conv_properties, moist=_moist_mode(moist))
 
 
 def storm_proxies(dat):
@@ -535,7 +576,8 @@ def storm_proxies(dat):
 
 # -- tables (pf.py:39-61) ------------------------------------------------------------------------------
 def load_moist_adiabat_lookups(**kwargs):
-    """pf.py:39: make the reference-format lookup tables available to moist='table' calls."""
+    """pf.py:39: load (or generate and cache) the reference-format lookup tables; from here on every moist call of this
+    module uses them, as in the reference."""
     from . import adiabat_tables
     adiabat_tables.load_moist_adiabat_lookups(**kwargs)
 
