@@ -192,6 +192,18 @@ int xp_cape_cin(const xp_view *pressure, const xp_view *temperature, const xp_vi
                 const xp_parcel *parcel, const xp_opts *opts,
                 xp_scalars_out *scalars, xp_profile_out *profile, void *stream);
 
+/* Several parcels of the SAME grid in one call -- what the reference's products do with three calls over the same three
+   arrays: most_unstable_cape_cin + mixed_layer_cape_cin (BASELINE config 5; pf.py:1557, 1651), and the most-unstable,
+   100 hPa and 50 hPa mixed-layer parcels of conv_properties (pf.py:1984-2006).  parcels[i] / scalars[i] / profiles[i]
+   (profiles may be NULL) describe parcel i, nparcel = 1...3.  Results are bit-identical to nparcel separate xp_cape_cin
+   calls.  With XP_MOIST_FAMILY, dewpoint input, surface / most-unstable / mixed-layer parcels and no profile arrays
+   requested (profiles NULL, or only their lifted_index set) the parcels are lifted in ONE pass over the grid: every
+   level is read once and its ln p and environment virtual temperature are evaluated once for all parcels
+   (csrc/xp_multi.hpp); any other combination runs the parcels one after the other inside the call. */
+int xp_cape_cin_multi(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint,
+                      int32_t nparcel, const xp_parcel *parcels, const xp_opts *opts,
+                      xp_scalars_out *scalars, xp_profile_out *profiles, void *stream);
+
 /* --- component entry points (used by the KATs and by the host-side mirrors) ------------------- */
 
 /* pf.py:609-682 lcl: n parcels -> LCL pressure / temperature / virtual temperature. */

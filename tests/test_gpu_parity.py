@@ -45,6 +45,15 @@ FKEYS = ('cape', 'cin', 'lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperat
 IKEYS = ('lfc_index', 'el_index', 'status', 'parcel_index')
 
 
+def _log_ties(n_excluded, n_label, n_saturated, n):
+    # evidence for the bounds below: every classification is appended to gpurun_out/ties.log when that directory exists
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'ties.log'), 'a') as fh:
+            fh.write('%s excluded=%d label_only=%d saturated=%d n=%d\n' % (os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], n_excluded, n_label, n_saturated, n))
+
+
 def _saturated_tie_columns(got, ref):
     """Columns whose disagreement is the reference's own rounding noise, not the kernel's.
 
@@ -58,7 +67,7 @@ def _saturated_tie_columns(got, ref):
       (b) the SIGN of that difference, i.e. whether a crossing is seen on the LCL at all: a different LFC altogether.
           Both outcomes are "the reference's result".  Measured: about 4 % of SATURATED columns (device-library vs glibc
           exp/log differ in the last bit for that fraction of inputs); the synthetic correctness grids hold 3 % saturated
-          columns, so such columns must stay below 0.125 % of the grid (label ties: 0.5 %), and they are left out of the comparison.
+          columns, so such columns are bounded as a fraction of the saturated ones (below), and they are left out of the comparison.
     Everything else must agree exactly.  Returns (label_only, excluded) boolean masks."""
     lcl = ref['lcl_pressure']
     lcl_on_parcel = lcl == np.asarray(got['parcel_pressure'], dtype=np.float64)
@@ -77,9 +86,14 @@ def _saturated_tie_columns(got, ref):
                      (np.abs(ref['el_pressure'] - lcl) <= 1e-9 * lcl))
     el_tie = lcl_on_parcel & (ge != re_) & el_on_lcl
     excluded = (tie & ~label_only) | el_tie
-    # measured rate of either class: ~0.12 % of a grid with 3 % saturated columns (round-2 soak)
-    assert excluded.sum() <= max(2, tie.size // 800), ('too many saturated-parcel sign ties', int(excluded.sum()))
-    assert label_only.sum() <= max(4, tie.size // 200), ('too many LCL-label ties', int(label_only.sum()))
+    _log_ties(int(excluded.sum()), int(label_only.sum()), int(lcl_on_parcel.sum()), tie.size)
+    # Bounds, as fractions of the SATURATED columns of the grid (the only ones that can tie).  Measured on the GPU box
+    # (gpurun_out/ties.log of the round-3 run, every classification of this suite): sign ties 0-1.1 % of the saturated
+    # columns on full-depth grids and up to 6.3 % (10 of 159) on the 1...8-level truncated grids, where the LCL crossing
+    # is most of the column; label ties 4.6-5.3 % (e.g. 19 of 370, 33 of 652).  A broken tie rule shows up as ~40 %.
+    n_sat = int(lcl_on_parcel.sum())
+    assert excluded.sum() <= max(2, -(-7 * n_sat // 100)), ('too many saturated-parcel sign ties', int(excluded.sum()), n_sat)
+    assert label_only.sum() <= max(4, -(-8 * n_sat // 100)), ('too many LCL-label ties', int(label_only.sum()), n_sat)
     return label_only, excluded
 
 

@@ -19,7 +19,7 @@ HUMIDITY = {'dewpoint': 0, 'specific': 1}
 ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 
 # every symbol include/xparcel.h declares
-SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_lcl', 'xp_dry_lapse',
+SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_cape_cin_multi', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
            'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_interp_levels', 'xp_dewpoint_from_specific_humidity',
            'xp_crossing_level', 'xp_mixing_ratio', 'xp_last_error')
@@ -86,9 +86,17 @@ TU_FLAGS = {0: [], 1: [], 2: ['-DXP_CAPE_THREADS=1024', '-mllvm', '-disable-mach
 for _m in list(TU_FLAGS):
     if os.environ.get(f'XP_TU_FLAGS_{_m}') is not None:
         TU_FLAGS[_m] = os.environ[f'XP_TU_FLAGS_{_m}'].split()
+# The fused several-parcels kernel (csrc/xp_multi.hpp), one unit per (dtype, number of parcels): workgroup size and LDS
+# slot fields per chain such that 58.6 KB of tables + NP x fields x threads x 8 B fit the CU's 160 KB.
+MULTI_FLAGS = {2: ['-DXP_CAPE_THREADS=512', '-DXP_SLOT_FIELDS=12', '-mllvm', '-disable-machine-licm']}
+for _m in list(MULTI_FLAGS):
+    if os.environ.get(f'XP_MULTI_FLAGS_{_m}') is not None:
+        MULTI_FLAGS[_m] = os.environ[f'XP_MULTI_FLAGS_{_m}'].split()
 UNITS = [('xparcel', 'xparcel.hip', [])] + [
     (f'cape_{t[0]}{m}', 'xp_cape_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_TU_MODE={m}'] + TU_FLAGS[m])
-    for t in ('double', 'float') for m in (0, 1, 2)]
+    for t in ('double', 'float') for m in (0, 1, 2)] + [
+    (f'multi_{t[0]}{n}', 'xp_multi_tu.hip', [f'-DXP_TU_T={t}', f'-DXP_MULTI_NP={n}'] + MULTI_FLAGS[n])
+    for t in ('double', 'float') for n in sorted(MULTI_FLAGS)]
 
 
 def build(force=False, verbose=False, jobs=None):

@@ -654,7 +654,10 @@ struct Family {
 #ifndef XP_CAPE_THREADS
 #define XP_CAPE_THREADS 256
 #endif
-constexpr int SLOT_STRIDE = XP_CAPE_THREADS, SLOT_FIELDS = XP_CAPE_THREADS >= 1024 ? 12 : 13;   // (the 1024-thread family workgroups have no LDS left for SL_LI)
+#ifndef XP_SLOT_FIELDS
+#define XP_SLOT_FIELDS (XP_CAPE_THREADS >= 1024 ? 12 : 13)    // (the 1024-thread family workgroups have no LDS left for SL_LI)
+#endif
+constexpr int SLOT_STRIDE = XP_CAPE_THREADS, SLOT_FIELDS = XP_SLOT_FIELDS;
 // SL_A0..A3 are used twice: below the LCL they hold the lower bracket of the LCL interpolation (kernel side:
 // pressure, ln p, T, Td of the last valid level), from the LCL node on the bottom-LFC record -- an LFC has to lie
 // above the LCL (pf.py:1127-1132), so the two never coexist; the LCL node re-initialises them.

@@ -65,7 +65,7 @@ struct Parcel { double p, t, td; int64_t first; int idx; bool prepend; };
 // most_unstable_parcel (pf.py:102-135 with get_layer pf.py:63-100 and bound_pressure pf.py:208-227):
 // highest theta-e in the lowest `depth` hPa, first maximum wins; the layer top is the level closest to
 // p_bottom - depth (ties -> higher pressure).
-template <typename T, bool HUM> XP_DEV Parcel select_mu_exact(const CapeArgs &a, int64_t c, const double *es) {
+template <typename T, bool HUM> XP_DEV Parcel select_mu_exact(const CapeArgs &a, int64_t c, const double *es, const double depth) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
     // one-level software prefetch: the loop is otherwise a chain of dependent HBM round trips
@@ -74,7 +74,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_mu_exact(const CapeArgs &a,
         double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
         if (isnan_(p)) continue;
-        if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
+        if (isnan_(bottom)) { bottom = p; bound = bottom - depth; }
         double d = fabs(p - bound);
         bool below = p < bound;
         if (below && !(d < dmin)) break;                  // the level above the bound is at least as close
@@ -100,7 +100,7 @@ XP_DEV float ln_theta_e_f32(float p, float t, float td) {
 // more than MU_F32_WINDOW (several times the fp32 error) it is the fp64 argmax too and is taken as it stands, otherwise
 // (a near tie, ~0.1 % of columns) the column repeats the search in fp64 -- same parcel as the oracle either way.
 constexpr float MU_F32_WINDOW = 2e-5f;
-template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es) {
+template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64_t c, const double *es, const double depth) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan();
     float best = -__builtin_inff(), second = -__builtin_inff();
@@ -130,7 +130,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64
             if (done || k >= a.nlev) continue;
             double p = (double)cp[j], t = (double)ct[j], td = as_dewpoint<HUM>(es, p, t, (double)cd[j]);
             if (isnan_(p)) continue;
-            if (isnan_(bottom)) { bottom = p; bound = bottom - a.depth; }
+            if (isnan_(bottom)) { bottom = p; bound = bottom - depth; }
             double d = fabs(p - bound);
             bool below = p < bound;
             if (below && !(d < dmin)) { done = true; continue; }
@@ -146,7 +146,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_mu(const CapeArgs &a, int64
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;               // the whole wavefront has left the layer
     }
     bool unsure = odd || (any && !(best - second > MU_F32_WINDOW));
-    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull && unsure) r = select_mu_exact<T, HUM>(a, c, es);
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull && unsure) r = select_mu_exact<T, HUM>(a, c, es, depth);
     return r;
 }
 
@@ -160,7 +160,7 @@ XP_DEV double interp_rule(double xb, double xa, double at, double cb, double ca)
     double res = xb + (xa - xb) * fdiv(at - cb, ca - cb);
     return (xb == xa) ? xb : res;
 }
-template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c, const double *es) {
+template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64_t c, const double *es, const double depth) {
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = true;
     double p_start = ld<T>(a.p, 0, c);
     double bottom = qnan(), top = qnan();
@@ -172,7 +172,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
     for (int64_t k = 0; k < a.nlev; ++k) {
         double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
         if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
-        if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - a.depth; }
+        if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - depth; }
         if (!isnan_(p) && p < top) {
             // insert the interpolated top row, close the integral; the profile continues from this level
             double lt = flog(top), cb = flog(pb), ca = flog(p);
@@ -196,8 +196,8 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
         layer_mean_step<T>(s_th, pp, thp, top, th_t);
         layer_mean_step<T>(s_w, pp, wp, top, w_t);
     }
-    double depth = fabs(top - bottom);
-    double th_m = (1.0 / depth) * s_th, w_m = (1.0 / depth) * s_w;
+    double dlay = fabs(top - bottom);
+    double th_m = (1.0 / dlay) * s_th, w_m = (1.0 / dlay) * s_w;
     r.p = p_start;                                                         // pf.py:250, 287
     r.t = th_m * fpow(p_start / 1000.0, KAPPA);                             // pf.py:268-269
     r.td = dewpoint_of_e(vapor_pressure(p_start, w_m));                    // pf.py:275-280
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         pc.p = ld1<T>(a.ex_p, c); pc.t = ld1<T>(a.ex_t, c); pc.td = ld1<T>(a.ex_td, c);
         pc.first = 0; pc.idx = -1; pc.prepend = false;
     } else if (PMODE == PM_MU) {
-        pc = select_mu<T, HUM>(a, c, es);
+        pc = select_mu<T, HUM>(a, c, es, a.depth);
     } else {
-        pc = select_ml<T, HUM>(a, c, es);
+        pc = select_ml<T, HUM>(a, c, es, a.depth);
     }
 
     const bool vtc = DEF || (a.vtc != 0), pos_neg = DEF || (a.pos_neg != 0);
@@ -598,7 +598,7 @@ template <typename T, int PMODE> __global__ __launch_bounds__(256) void k_select
     const double *es = stage_es_table(a.es_tab, s_es);
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
-    Parcel pc = (PMODE == PM_MU) ? select_mu<T, false>(a, c, es) : select_ml<T, false>(a, c, es);
+    Parcel pc = (PMODE == PM_MU) ? select_mu<T, false>(a, c, es, a.depth) : select_ml<T, false>(a, c, es, a.depth);
     st(a.s.par_p, a.s.f64, c, pc.p); st(a.s.par_t, a.s.f64, c, pc.t); st(a.s.par_td, a.s.f64, c, pc.td);
     sti(a.s.parcel_idx, c, pc.idx);
 }

@@ -13,6 +13,7 @@
 
 #include "../../include/xparcel.h"
 #include "xp_kernels.hpp"
+#include "xp_multi.hpp"
 
 namespace {
 
@@ -525,6 +526,63 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
     }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
     else launch_cape_pm<float>(a, parcel->mode, profile != nullptr, st.s);
+    return st.finish();
+}
+
+namespace {
+bool multi_fused_ok(int32_t np, const xp_parcel *parcels, const xp_opts *o, const xp_profile_out *profiles) {
+    static const bool off = getenv("XP_MULTI_SEQUENTIAL") != nullptr;        // A/B: force the one-after-the-other path
+    if (off || !o || o->moist_mode != XP_MOIST_FAMILY || o->humidity != XP_HUM_DEWPOINT) return false;
+    if (np != 2) return false;                                               // instantiated parcel counts (xp_multi_tu.hip)
+    for (int i = 0; i < np; ++i) {
+        if (parcels[i].mode != XP_PARCEL_SURFACE && parcels[i].mode != XP_PARCEL_MOST_UNSTABLE && parcels[i].mode != XP_PARCEL_MIXED_LAYER) return false;
+        if (profiles) return false;
+    }
+    return true;
+}
+}  // namespace
+
+int xp_cape_cin_multi(const xp_view *p, const xp_view *t, const xp_view *td, int32_t np, const xp_parcel *parcels,
+                      const xp_opts *o, xp_scalars_out *scalars, xp_profile_out *profiles, void *stream) {
+    if (np < 1 || np > xp::MULTI_MAX) return fail(XP_E_ARG, "xp_cape_cin_multi: 1...%d parcels", xp::MULTI_MAX);
+    if (!parcels || !scalars) return fail(XP_E_ARG, "xp_cape_cin_multi: null parcels / scalars");
+    if (!multi_fused_ok(np, parcels, o, profiles)) {
+        for (int i = 0; i < np; ++i) {
+            int rc = xp_cape_cin(p, t, td, &parcels[i], o, &scalars[i], profiles ? &profiles[i] : nullptr, stream);
+            if (rc) return rc;
+        }
+        return XP_OK;
+    }
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    Stager st(stream);
+    xp::MultiArgs m;
+    memset(&m, 0, sizeof(m));
+    if ((rc = fill_common(st, p, t, td, &parcels[0], o, &m.base))) return rc;
+    m.np = np;
+    const int64_t ncol = m.base.ncol;
+    for (int i = 0; i < np; ++i) {
+        m.mode[i] = parcels[i].mode;                                         // XP_PARCEL_* == xp::PM_*
+        m.depth[i] = parcels[i].depth;
+        if ((rc = stage_scalars(st, &scalars[i], ncol, &m.s[i]))) return rc;
+    }
+    if (ncol == 0) return st.finish();
+    void *flags = nullptr;
+    HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)ncol * (size_t)np, st.s));
+    st.scratch.push_back(flags);
+    for (int i = 0; i < np; ++i) m.flags[i] = (int32_t *)flags + (size_t)i * (size_t)ncol;
+    static const long long persist_env = [] { const char *e = getenv("XP_PERSIST_MIN_COLS"); return e ? atoll(e) : -1ll; }();
+    m.base.persist = (long long)ncol >= (persist_env >= 0 ? persist_env : (1ll << 19)) && ncol < (1ll << 36);
+    const bool f64 = p->dtype == XP_F64;
+    if (f64) xp::launch_cape_multi<double, 2>(m, st.s); else xp::launch_cape_multi<float, 2>(m, st.s);
+    // columns a chain's family table could not serve: the single-parcel RK4 kernel redoes them, chain by chain
+    for (int i = 0; i < np; ++i) {
+        xp::CapeArgs b = m.base;
+        b.depth = m.depth[i]; b.s = m.s[i]; b.flags = m.flags[i]; b.only_flagged = 1; b.persist = 0;
+        if (f64) xp::launch_cape_mode<double, 0>(b, m.mode[i], false, st.s);
+        else xp::launch_cape_mode<float, 0>(b, m.mode[i], false, st.s);
+    }
     return st.finish();
 }
 

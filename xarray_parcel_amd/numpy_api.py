@@ -212,6 +212,48 @@ def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=No
     return res
 
 
+def cape_cin_multi(pressure, temperature, dewpoint, parcels, want=None, moist=None, lifted_index_at=None, **kwargs):
+    """Several parcels of one grid in ONE call (xp_cape_cin_multi): `parcels` is a sequence of names or (name, depth)
+    pairs out of 'surface', 'most_unstable', 'mixed_layer' -- e.g. [('most_unstable', 300), ('mixed_layer', 100)] for
+    BASELINE config 5, [('most_unstable', 250), ('mixed_layer', 100), ('mixed_layer', 50)] for conv_properties
+    (pf.py:1984-2006).  Returns one dict per parcel, bit-identical to what cape_cin_columns() returns for it; with
+    moist='family' and dewpoint input the parcels share one pass over the grid."""
+    (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
+    assert p.shape == t.shape == td.shape, 'pressure, temperature, dewpoint must share a shape'
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    o = _opts(moist=moist or _DEFAULT['moist'], **kwargs)
+    specs = []
+    for pc in parcels:
+        name, depth = (pc, None) if isinstance(pc, str) else (pc[0], pc[1])
+        assert name in ('surface', 'most_unstable', 'mixed_layer'), 'parcels: surface, most_unstable or mixed_layer'
+        if depth is None:
+            depth = 300.0 if name == 'most_unstable' else 100.0                # pf.py:1558, 1652
+        specs.append((name, float(depth)))
+    n = len(specs)
+    pcs = (L.Parcel * n)(*[L.Parcel(L.PARCEL[nm], 0, dp, None, None, None) for nm, dp in specs])
+    sos = (L.ScalarsOut * n)()
+    pos = (L.ProfileOut * n)() if lifted_index_at is not None else None
+    names = L.SCALAR_F + L.SCALAR_I + L.SCALAR_P if want is None else tuple(want)
+    outs = []
+    for i in range(n):
+        sos[i].dtype, sos[i].mem = p.xp_dtype, p.mem
+        out = {}
+        for k in names:
+            arr, ptr = _alloc((ncol,), np.int32 if k in L.SCALAR_I else dt, dev, p)
+            setattr(sos[i], k, ptr)
+            out[k] = arr
+        if pos is not None:
+            pos[i].dtype, pos[i].mem, pos[i].nlev_out, pos[i].lev_stride, pos[i].col_stride = p.xp_dtype, p.mem, nlev + 1, ncol, 1
+            arr, ptr = _alloc((ncol,), dt, dev, p)
+            pos[i].lifted_index, pos[i].lifted_index_pressure = ptr, float(lifted_index_at)
+            out['lifted_index'] = arr
+        outs.append(out)
+    L.check(lib.xp_cape_cin_multi(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)), C.byref(_view(td, nlev, ncol)),
+                                  C.c_int32(n), pcs, C.byref(o), sos, pos, _stream(dev)))
+    return [{k: v.reshape(hshape) for k, v in out.items()} for out in outs]
+
+
 # ---- reference-named functions (one column or a grid) -----------------------------------------
 def _split(res):
     cc = {'cape': res['cape'], 'cin': res['cin']}
