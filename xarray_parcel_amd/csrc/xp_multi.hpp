@@ -196,6 +196,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
             v.P = pc.p; v.X = log_tab<true>(es, pc.p); v.T = pc.t; v.Td = pc.td;
             v.tve = env_tv(pc.t, pc.td, pc.p);
             feed(h, v, false, false);
+            // a supersaturated mixed parcel lies above its own LCL: the LCL node went first and the parcel node follows it
+            const bool again = h.done;
+            if (__builtin_amdgcn_ballot_w64(again) != 0ull && again) feed(h, v, true, false);
         }
     });
 
@@ -242,8 +245,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
                     h.sc.template node<false, true>(prev.P, prev.X, vtc ? tvp : tp, vtc ? prev.tve : prev.T, false);
                 }
             } else {
+                // (a chain that is past its LCL consumes level k - 1, which has to belong to its profile too)
                 const bool skew = h.done;
-                if (k >= h.first) {
+                if (k >= h.first + (skew ? 1 : 0)) {
                     Lev v;
                     v.P = skew ? prev.P : cur.P; v.X = skew ? prev.X : cur.X; v.T = skew ? prev.T : cur.T;
                     v.Td = skew ? prev.Td : cur.Td; v.tve = skew ? prev.tve : cur.tve;
