@@ -87,13 +87,14 @@ def _saturated_tie_columns(got, ref):
     el_tie = lcl_on_parcel & (ge != re_) & el_on_lcl
     excluded = (tie & ~label_only) | el_tie
     _log_ties(int(excluded.sum()), int(label_only.sum()), int(lcl_on_parcel.sum()), tie.size)
-    # Bounds, as fractions of the SATURATED columns of the grid (the only ones that can tie).  Measured on the GPU box
-    # (gpurun_out/ties.log of the round-3 run, every classification of this suite): sign ties 0-1.1 % of the saturated
-    # columns on full-depth grids and up to 6.3 % (10 of 159) on the 1...8-level truncated grids, where the LCL crossing
-    # is most of the column; label ties 4.6-5.3 % (e.g. 19 of 370, 33 of 652).  A broken tie rule shows up as ~40 %.
+    # Bounds.  Only saturated columns can tie, so the bounds are fractions of THEIR number (and never looser than round
+    # 2's fractions of the grid).  Measured on the GPU box (gpurun_out/ties.log of the round-3 runs, every classification
+    # of this suite): sign ties 0-1.1 % of the saturated columns on full-depth grids and up to 6.3 % (10 of 159) on the
+    # 1...8-level truncated grids, where the LCL crossing is most of the column; label ties 4.6-5.3 % on 12 000-20 000
+    # column grids (19 of 370, 33 of 652) and up to 9.9 % on small ones (16 of 162).  A broken tie rule shows up as ~40 %.
     n_sat = int(lcl_on_parcel.sum())
-    assert excluded.sum() <= max(2, -(-7 * n_sat // 100)), ('too many saturated-parcel sign ties', int(excluded.sum()), n_sat)
-    assert label_only.sum() <= max(4, -(-8 * n_sat // 100)), ('too many LCL-label ties', int(label_only.sum()), n_sat)
+    assert excluded.sum() <= max(2, min(tie.size // 400, -(-10 * n_sat // 100))), ('too many saturated-parcel sign ties', int(excluded.sum()), n_sat)
+    assert label_only.sum() <= max(4, min(tie.size // 100, -(-15 * n_sat // 100))), ('too many LCL-label ties', int(label_only.sum()), n_sat)
     return label_only, excluded
 
 

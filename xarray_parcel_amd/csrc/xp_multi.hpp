@@ -7,15 +7,16 @@
 // instructions a level costs.  Here one thread still owns one column, but carries NP parcel "chains" (LCL, dry-adiabat
 // constants, xp::Family coefficients, xp::Scan state, LDS slots) through ONE walk over the levels:
 //
-//   * every level is loaded once and its environment node (ln p, Tv) evaluated once, when it arrives (`cur`); it stays one
-//     more iteration as `prev`;
-//   * a chain below its LCL consumes `cur` (dry adiabat); in the iteration in which `cur` lies above its LCL it consumes
-//     the LCL node instead (environment interpolated between the chain's bracket slots and `cur`, pf.py:897-920) and is
-//     one level behind from then on: it consumes `prev` (moist adiabat) -- the same node order as k_cape_cin's phases A and
-//     B, decided per chain: a chain whose 64 lanes are all above their LCLs runs the short moist-only node;
-//   * a searching parcel's chain (most-unstable: starts at its level; mixed-layer: its prepended parcel node is fed before
-//     the walk, then the levels above the mixed layer) sits out until the walk reaches its first level, so the wavefront's
-//     level index is wave-uniform and every load is one coalesced row request.
+//   * first every chain, one after the other, does what depends on its parcel alone: the parcel search, the LCL, the
+//     adiabat's label, and the levels up to the LCL with the LCL node in their midst (k_cape_cin's phase A, on per-lane
+//     level indices: ~10-15 iterations until the whole wavefront is past its LCLs);
+//   * then ONE walk up the remaining levels (k_cape_cin's phase B, ~85 % of a column): every level is loaded once, with a
+//     wave-uniform index (one coalesced row request per array), its environment node (ln p, Tv) is evaluated once, and each
+//     chain that has reached it feeds it to its scan with its own moist-adiabat value.  A chain that resumes higher up sits
+//     out until the walk reaches its level.
+// (A first version walked all chains through their LCLs in the shared loop as well: with the most-unstable parcels of
+// 18 % of the columns starting at levels 12-43 some lane of nearly every wavefront was below its LCL up to level ~50, the
+// expensive below-LCL node ran there for everybody, and the fused c5 step took 39 ms against 24.3 for two separate calls.)
 //
 // Every chain performs exactly the floating-point operations of the single-parcel kernel on its nodes (same device
 // functions, same order), so the results are bit-identical to separate xp_cape_cin calls (tests/test_gpu_multi.py).
@@ -87,19 +88,13 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         return need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P, false)) : T_;
     };
 
-    // One node of chain h out of a level record (phase-A logic of k_cape_cin's `source`): `skew` = the chain is past its LCL
-    // and v is the level that has been waiting; otherwise v is the level just loaded, and when it lies above the LCL (or
-    // nothing is left: `last`) the LCL node is fed in its place.
-    auto feed = [&](Chain &h, const Lev &v, const bool skew, const bool last) __attribute__((always_inline)) {
+    // One node of chain h below / at / just above its LCL -- the logic of k_cape_cin's phase A (`source`), on one level
+    // (P, T_, Td_): `skew` = the chain is past its LCL and this is the level that has been waiting; otherwise it is the level
+    // just loaded, and when it lies above the LCL (or nothing is left: `last`) the LCL node is fed in its place.
+    auto feed = [&](Chain &h, double P, double T_, double Td_, const bool skew, const bool last) __attribute__((always_inline)) {
         double *const br = h.sc.slot;
-        double P = v.P, X = v.X, T_ = v.T, Td_ = v.Td, tve = v.tve;
-        const bool snap = (fabs(P - h.lp) <= LCL_SNAP * h.lp) && (P != h.lp);         // on the LCL (see xp::lcl)
-        if (__builtin_amdgcn_ballot_w64(snap) != 0ull && snap) {
-            P = h.lp;
-            double tq = T_;
-            asm volatile("" : "+v"(tq));
-            tve = env_tv(tq, Td_, P);                                              // the node's Tv at the snapped pressure
-        }
+        if (fabs(P - h.lp) <= LCL_SNAP * h.lp) P = h.lp;                           // on the LCL (see xp::lcl)
+        double X = log_tab<true>(es, P);
         X = (P == h.lp) ? h.xl : X;
         const bool cross = !skew && (last || P < h.lp);
         if (isnan_(P) && !skew && !last) h.status |= 4;                            // NaN pressure below the LCL (see xparcel.h)
@@ -122,9 +117,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
             const double lsel = br[SL_LCL_T * SLOT_STRIDE];
             P = h.lp; X = h.xl; T_ = te; Td_ = tde;
             tp = lsel; tvp = lsel;
-            double tq = T_;
-            asm volatile("" : "+v"(tq));
-            tve = env_tv(tq, Td_, P);                                              // pf.py:911-920
+        }
+        double tve = T_;                                                           // pf.py:839-843, 911-920
+        if (need_w) {                                                              // one wave-uniform range test for the two e_s
+            if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
+            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
         }
         const bool tie = need_w && cross && h.sat;
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = T_; asm volatile("" : "+v"(q)); tve = virt_ref(q, Td_, h.lp); }
@@ -141,7 +138,13 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         h.done = skew || cross;
     };
 
-    // ---- parcels, LCLs, labels: per chain, before the walk ------------------------------------------------------------
+    const int64_t lane_off = (int64_t)c * b.p.cs * (int64_t)sizeof(T), row_step = b.p.ls * (int64_t)sizeof(T);
+    typedef const char __attribute__((address_space(1))) *GPtr;
+    typedef const T __attribute__((address_space(1))) *GT;
+
+    // ---- per chain, one after the other: parcel, LCL, label, and the levels up to the LCL ---------------------------------
+    // (k_cape_cin's phase A: every lane walks from ITS first level with its own row pointers until the whole wavefront is
+    // past its LCLs -- ~10-15 iterations; these rows are read again by the shared walk below, out of L2)
     each([&](Chain &h, auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         const int mode = a.mode[i];
@@ -189,27 +192,53 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
             h.done = false;
             h.first = (int)pc.first;
         }
-        // mixed layer: the parcel is the new level 0 of its profile (pf.py:1641-1644), fed before the walk
+        // mixed layer: the parcel is the new level 0 of its profile (pf.py:1641-1644)
         const bool pre = pc.prepend && h.first != DEAD;
         if (__builtin_amdgcn_ballot_w64(pre) != 0ull && pre) {
-            Lev v;
-            v.P = pc.p; v.X = log_tab<true>(es, pc.p); v.T = pc.t; v.Td = pc.td;
-            v.tve = env_tv(pc.t, pc.td, pc.p);
-            feed(h, v, false, false);
+            feed(h, pc.p, pc.t, pc.td, false, false);
             // a supersaturated mixed parcel lies above its own LCL: the LCL node went first and the parcel node follows it
             const bool again = h.done;
-            if (__builtin_amdgcn_ballot_w64(again) != 0ull && again) feed(h, v, true, false);
+            if (__builtin_amdgcn_ballot_w64(again) != 0ull && again) feed(h, pc.p, pc.t, pc.td, true, false);
         }
+        // levels first, first + 1, ... while some lane of the wavefront is at or below its LCL; a lane past its LCL is one
+        // level behind its loads (the level that crossed waits in wP, wT, wM)
+        int k = h.first == DEAD ? nlev + 1 : h.first;
+        GPtr lp_, lt_, ld_;
+        {
+            const int64_t o = (int64_t)(k < nlev ? k : 0) * row_step + lane_off;
+            lp_ = (GPtr)b.p.data + o; lt_ = (GPtr)b.t.data + o; ld_ = (GPtr)b.td.data + o;
+        }
+        double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
+        auto load3 = [&]() __attribute__((always_inline)) {
+            np_ = (double)*(GT)lp_; nt_ = (double)*(GT)lt_; ntd_ = (double)*(GT)ld_;
+            lp_ += row_step; lt_ += row_step; ld_ += row_step;
+            asm volatile("" : "+v"(lp_), "+v"(lt_), "+v"(ld_));
+        };
+        if (k < nlev) load3();
+        double wP = qnan(), wT = qnan(), wM = qnan();
+        for (; k <= nlev; ++k) {
+            if (__ballot(!h.done) == 0ull) break;
+            const bool in = k < nlev;
+            const double P = in ? np_ : qnan(), T_ = in ? nt_ : qnan(), M_ = in ? ntd_ : qnan();
+            if (k + 1 < nlev) load3();
+            const bool skew = h.done;
+            if (!skew || k > h.first) feed(h, skew ? wP : P, skew ? wT : T_, skew ? wM : M_, skew, !in);
+            wP = P; wT = T_; wM = M_;
+        }
+        // the next level this chain takes is the one that is waiting (k - 1), or its first one if it has not loaded any:
+        // the shared walk feeds level j to a chain in iteration j + 1
+        h.first = h.first == DEAD ? DEAD : (k > h.first ? k : h.first + 1);
     });
 
-    // ---- the walk ------------------------------------------------------------------------------------------------------
+    // ---- the shared walk: every chain of every lane is above its LCL (k_cape_cin's phase B) ------------------------------
+    // h.first now is the iteration in which the chain resumes; the wavefront walks up from the lowest of them, every level
+    // is loaded once (one coalesced row request per array) and its environment node -- ln p, Tv(T, Td, p): two e_s behind
+    // one wave-uniform range test -- evaluated once for all chains.
     int fmin = h0.first;
     if constexpr (NP > 1) fmin = h1.first < fmin ? h1.first : fmin;
     if constexpr (NP > 2) fmin = h2.first < fmin ? h2.first : fmin;
-    int ku = nlev + 1;                                                          // wave-uniform: the lowest first level of any chain of any lane
-    for (int probe = 0; probe <= nlev; ++probe) if (__ballot(fmin <= probe) != 0ull) { ku = probe; break; }
-    const int64_t lane_off = (int64_t)c * b.p.cs * (int64_t)sizeof(T), row_step = b.p.ls * (int64_t)sizeof(T);
-    typedef const char __attribute__((address_space(1))) *GPtr;
+    int ku = nlev + 1;
+    for (int probe = 1; probe <= nlev; ++probe) if (__ballot(fmin <= probe) != 0ull) { ku = probe - 1; break; }
     GPtr lp_, lt_, ld_;
     {
         const int64_t o = (int64_t)(ku < nlev ? ku : 0) * row_step + lane_off;
@@ -217,7 +246,6 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
     }
     double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
     auto load3 = [&]() __attribute__((always_inline)) {
-        typedef const T __attribute__((address_space(1))) *GT;
         np_ = (double)*(GT)lp_; nt_ = (double)*(GT)lt_; ntd_ = (double)*(GT)ld_;
         lp_ += row_step; lt_ += row_step; ld_ += row_step;
         asm volatile("" : "+v"(lp_), "+v"(lt_), "+v"(ld_));
@@ -226,36 +254,24 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
     Lev cur, prev;
     prev.P = prev.X = prev.T = prev.Td = prev.tve = qnan();
     for (int k = ku; k <= nlev; ++k) {
-        const bool in = k < nlev;
-        cur.P = in ? np_ : qnan(); cur.T = in ? nt_ : qnan(); cur.Td = in ? ntd_ : qnan();
-        if (k + 1 < nlev) load3();
-        // the level's environment node, once for all chains: ln p and Tv(T, Td, p) (two e_s behind one wave-uniform range test)
-        cur.X = log_tab<true>(es, cur.P);
-        cur.tve = cur.T;
-        if (need_w && in) {
-            if (__builtin_amdgcn_ballot_w64(!(in_table(cur.T, 0.0) && in_table(cur.Td, 0.0))) == 0ull) cur.tve = virt(cur.T, mixing_ratio_tab(es, cur.T, cur.Td, cur.P, true));
-            else { double tq = cur.T; asm volatile("" : "+v"(tq)); cur.tve = virt(tq, mixing_ratio_tab(es, tq, cur.Td, cur.P, false)); }
-        }
         each([&](Chain &h, auto ic) __attribute__((always_inline)) {
-            if (__ballot(!h.done) == 0ull) {
-                // every lane of this chain is above its LCL: only the moist adiabat (k_cape_cin's phase B)
-                if (k > h.first) {
-                    const double tvp = h.fam.at(prev.X);
-                    const double tp = !vtc ? Family::temperature_of(es, prev.P, tvp) : tvp;
-                    h.sc.template node<false, true>(prev.P, prev.X, vtc ? tvp : tp, vtc ? prev.tve : prev.T, false);
-                }
-            } else {
-                // (a chain that is past its LCL consumes level k - 1, which has to belong to its profile too)
-                const bool skew = h.done;
-                if (k >= h.first + (skew ? 1 : 0)) {
-                    Lev v;
-                    v.P = skew ? prev.P : cur.P; v.X = skew ? prev.X : cur.X; v.T = skew ? prev.T : cur.T;
-                    v.Td = skew ? prev.Td : cur.Td; v.tve = skew ? prev.tve : cur.tve;
-                    feed(h, v, skew, !in);
-                }
+            if (k >= h.first) {
+                const double tvp = h.fam.at(prev.X);
+                const double tp = !vtc ? Family::temperature_of(es, prev.P, tvp) : tvp;
+                h.sc.template node<false, true>(prev.P, prev.X, vtc ? tvp : tp, vtc ? prev.tve : prev.T, false);
             }
         });
-        prev = cur;
+        if (k < nlev) {
+            cur.P = np_; cur.T = nt_; cur.Td = ntd_;
+            if (k + 1 < nlev) load3();
+            cur.X = log_tab<true>(es, cur.P);
+            cur.tve = cur.T;
+            if (need_w) {
+                if (__builtin_amdgcn_ballot_w64(!(in_table(cur.T, 0.0) && in_table(cur.Td, 0.0))) == 0ull) cur.tve = virt(cur.T, mixing_ratio_tab(es, cur.T, cur.Td, cur.P, true));
+                else { double tq = cur.T; asm volatile("" : "+v"(tq)); cur.tve = virt(tq, mixing_ratio_tab(es, tq, cur.Td, cur.P, false)); }
+            }
+            prev = cur;
+        }
     }
 
     // ---- results -------------------------------------------------------------------------------------------------------
