@@ -73,6 +73,9 @@ enum { XP_HUM_DEWPOINT = 0, XP_HUM_SPECIFIC = 1 };
    transparently redone with XP_MOIST_EXACT.  Honoured by xp_cape_cin; the component entry points treat it as
    XP_MOIST_EXACT. */
 enum { XP_LCL_INTERP_LINEAR = 0, XP_LCL_INTERP_LOG = 1 };
+/* xp_opts.flags.  XP_OPT_FUSE_PARCELS: xp_cape_cin_multi lifts its parcels in ONE pass over the grid where it can (see
+   there); same results bit for bit, measured SLOWER than one pass per parcel on MI355X, so off by default. */
+enum { XP_OPT_FUSE_PARCELS = 1 };
 
 /* error codes */
 enum {
@@ -124,7 +127,7 @@ typedef struct {
     int32_t moist_mode;                     /* XP_MOIST_* */
     int32_t compute;                        /* arithmetic type: XP_F64 (the only one implemented; XP_F32 is rejected with XP_E_ARG) */
     int32_t humidity;                       /* XP_HUM_*: what the `dewpoint` view of xp_cape_cin holds */
-    int32_t reserved;
+    int32_t flags;                          /* XP_OPT_* bits; 0 by default */
 } xp_opts;
 
 /* Per-column outputs; every pointer is nullable (not written when NULL).  Floating outputs have
@@ -196,10 +199,10 @@ int xp_cape_cin(const xp_view *pressure, const xp_view *temperature, const xp_vi
    arrays: most_unstable_cape_cin + mixed_layer_cape_cin (BASELINE config 5; pf.py:1557, 1651), and the most-unstable,
    100 hPa and 50 hPa mixed-layer parcels of conv_properties (pf.py:1984-2006).  parcels[i] / scalars[i] / profiles[i]
    (profiles may be NULL) describe parcel i, nparcel = 1...3.  Results are bit-identical to nparcel separate xp_cape_cin
-   calls.  With XP_MOIST_FAMILY, dewpoint input, surface / most-unstable / mixed-layer parcels and no profile arrays
-   requested (profiles NULL, or only their lifted_index set) the parcels are lifted in ONE pass over the grid: every
-   level is read once and its ln p and environment virtual temperature are evaluated once for all parcels
-   (csrc/xp_multi.hpp); any other combination runs the parcels one after the other inside the call. */
+   calls; by default that is also how the work is done (one pass per parcel, back to back on the stream).  With
+   XP_OPT_FUSE_PARCELS in opts->flags, and XP_MOIST_FAMILY, dewpoint input, two surface / most-unstable / mixed-layer
+   parcels and no profiles, the parcels are lifted in ONE pass (csrc/xp_multi.hpp): every level above the LCLs is read
+   once and its ln p and environment virtual temperature evaluated once for both. */
 int xp_cape_cin_multi(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint,
                       int32_t nparcel, const xp_parcel *parcels, const xp_opts *opts,
                       xp_scalars_out *scalars, xp_profile_out *profiles, void *stream);

@@ -26,7 +26,7 @@ for name, depth in parcels:
     sep[name] = r
     out['separate_' + name + '_ms'] = ms
 out['separate_sum_ms'] = sum(out['separate_' + n + '_ms'] for n, _ in parcels)
-ms, fused = timed(lambda: xa.cape_cin_multi(p, t, td, parcels, want=want, moist='family'))
+ms, fused = timed(lambda: xa.cape_cin_multi(p, t, td, parcels, want=want, moist='family', fused=True))
 out['fused_ms'] = ms
 alg = (3 * nlev * 4 + 2 * 4) * ncol
 out['fused_frac_of_8TBs_single_parcel_bytes'] = alg / ms / 1e6 / 8000
@@ -35,7 +35,7 @@ for (name, depth), g in zip(parcels, fused):
         a, b = g[k], sep[name][k]
         out[f'bitwise_{name}_{k}'] = bool(torch.equal(a, b) or (torch.equal(torch.isnan(a), torch.isnan(b)) and bool((a[~torch.isnan(a)] == b[~torch.isnan(b)]).all())))
 idx = torch.arange(0, ncol, 3001, device='cuda')
-full = xa.cape_cin_multi(p[:, idx].contiguous(), t[:, idx].contiguous(), td[:, idx].contiguous(), parcels, moist='family')
+full = xa.cape_cin_multi(p[:, idx].contiguous(), t[:, idx].contiguous(), td[:, idx].contiguous(), parcels, moist='family', fused=True)
 for (name, depth), g, f in zip(parcels, fused, full):
     ref = co.cape_cin_grid(p[:, idx].cpu().numpy(), t[:, idx].cpu().numpy(), td[:, idx].cpu().numpy(), parcel=name, depth=depth, moist='family')
     out[f'oracle_{name}'] = {'columns': int(idx.numel()),

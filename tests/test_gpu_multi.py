@@ -39,7 +39,7 @@ def test_fused_equals_separate_calls_bit_for_bit(xa, pset, mode, dtype):
     parcels = SETS[pset]
     for nlev, ncol, seed in ((48, 12000, 11 + mode), (9, 3000, 5), (100, 5000, 3)):
         p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed, nan_fraction=0.08, dtype=dtype)
-        got = xa.cape_cin_multi(p, t, td, parcels, moist='family', **kw)
+        got = xa.cape_cin_multi(p, t, td, parcels, moist='family', fused=True, **kw)
         for (name, depth), g in zip(parcels, got):
             ref = xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist='family', **kw)
             _same(g, ref, (name, depth, nlev))
@@ -48,7 +48,7 @@ def test_fused_equals_separate_calls_bit_for_bit(xa, pset, mode, dtype):
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_fused_vs_oracle(xa, dtype):
     p, t, td = synth.columns(nlev=64, ncol=20000, seed=23, nan_fraction=0.08, dtype=dtype)
-    got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family')
+    got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family', fused=True)
     for (name, depth), g in zip(SETS[0], got):
         ref = co.cape_cin_grid(p, t, td, parcel=name, depth=depth, moist='family')
         _compare(g, ref, dtype, 1e-6)
@@ -60,26 +60,28 @@ def test_fused_truncated_and_ragged_shapes(xa):
     full = synth.columns(nlev=64, ncol=6000, seed=41, nan_fraction=0.08, dtype=np.float64)
     for nlev in (1, 2, 3, 5, 8):
         p, t, td = (np.ascontiguousarray(v[:nlev]) for v in full)
-        got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family')
+        got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family', fused=True)
         for (name, depth), g in zip(SETS[0], got):
             _same(g, xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist='family'), (name, nlev))
     for ncol in (1, 63, 65, 511, 513, 1025):
         p, t, td = synth.columns(nlev=33, ncol=ncol, seed=ncol, nan_fraction=0.1, dtype=np.float32)
-        got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family')
+        got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family', fused=True)
         for (name, depth), g in zip(SETS[0], got):
             _same(g, xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist='family'), (name, ncol))
     import torch
     p, t, td = synth.columns_torch(40, (1 << 19) + 777, 'cuda', seed=9, dtype=torch.float32)
-    got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family', want=('cape', 'cin', 'lfc_index', 'el_index', 'parcel_index'))
+    got = xa.cape_cin_multi(p, t, td, SETS[0], moist='family', fused=True, want=('cape', 'cin', 'lfc_index', 'el_index', 'parcel_index'))
     for (name, depth), g in zip(SETS[0], got):
         ref = xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist='family', want=('cape', 'cin', 'lfc_index', 'el_index', 'parcel_index'))
         for k in ref:
             assert torch.equal(g[k], ref[k]) or torch.equal(torch.isnan(g[k]), torch.isnan(ref[k])), (name, k)
 
 
-def test_other_modes_run_the_parcels_one_after_the_other(xa):
-    """moist='exact' (and anything else the fused kernel does not serve) still answers through the same call."""
+def test_default_runs_the_parcels_one_after_the_other(xa):
+    """Without fused=True, and for anything the fused kernel does not serve (moist='exact', three parcels), the same call
+    answers with one pass per parcel."""
     p, t, td = synth.columns(nlev=30, ncol=3000, seed=2, nan_fraction=0.05, dtype=np.float64)
-    got = xa.cape_cin_multi(p, t, td, SETS[0] + [('surface', None)], moist='exact')
-    for (name, depth), g in zip(SETS[0] + [('surface', None)], got):
-        _same(g, xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist='exact'), (name,))
+    for moist, fused in (('exact', True), ('family', False), ('family', True)):
+        got = xa.cape_cin_multi(p, t, td, SETS[0] + [('surface', None)], moist=moist, fused=fused)
+        for (name, depth), g in zip(SETS[0] + [('surface', None)], got):
+            _same(g, xa.cape_cin_columns(p, t, td, parcel=name, depth=depth, moist=moist), (name,))

@@ -16,6 +16,7 @@ PARCEL = {'surface': 0, 'most_unstable': 1, 'mixed_layer': 2, 'explicit': 3}
 MOIST = {'exact': 0, 'table': 1, 'family': 2}
 LCL_INTERP = {'linear': 0, 'log': 1}
 HUMIDITY = {'dewpoint': 0, 'specific': 1}
+OPT_FUSE_PARCELS = 1
 ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 
 # every symbol include/xparcel.h declares
@@ -38,7 +39,7 @@ class Parcel(C.Structure):
 class Opts(C.Structure):
     _fields_ = [('virtual_temperature_correction', C.c_int32), ('lcl_interp', C.c_int32),
                 ('pos_cape_neg_cin', C.c_int32), ('post_zero_cin', C.c_int32), ('moist_mode', C.c_int32),
-                ('compute', C.c_int32), ('humidity', C.c_int32), ('reserved', C.c_int32)]
+                ('compute', C.c_int32), ('humidity', C.c_int32), ('flags', C.c_int32)]
 
 
 SCALAR_F = ('cape', 'cin', 'lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature', 'lfc_pressure',

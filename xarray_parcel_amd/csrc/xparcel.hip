@@ -531,8 +531,9 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
 
 namespace {
 bool multi_fused_ok(int32_t np, const xp_parcel *parcels, const xp_opts *o, const xp_profile_out *profiles) {
-    static const bool off = getenv("XP_MULTI_SEQUENTIAL") != nullptr;        // A/B: force the one-after-the-other path
-    if (off || !o || o->moist_mode != XP_MOIST_FAMILY || o->humidity != XP_HUM_DEWPOINT) return false;
+    static const bool force = getenv("XP_MULTI_FUSED") != nullptr;           // A/B: fuse whenever possible
+    if (!o || o->moist_mode != XP_MOIST_FAMILY || o->humidity != XP_HUM_DEWPOINT) return false;
+    if (!force && !(o->flags & XP_OPT_FUSE_PARCELS)) return false;
     if (np != 2) return false;                                               // instantiated parcel counts (xp_multi_tu.hip)
     for (int i = 0; i < np; ++i) {
         if (parcels[i].mode != XP_PARCEL_SURFACE && parcels[i].mode != XP_PARCEL_MOST_UNSTABLE && parcels[i].mode != XP_PARCEL_MIXED_LAYER) return false;

@@ -212,17 +212,19 @@ def cape_cin_columns(pressure, temperature, dewpoint, parcel='surface', depth=No
     return res
 
 
-def cape_cin_multi(pressure, temperature, dewpoint, parcels, want=None, moist=None, lifted_index_at=None, **kwargs):
+def cape_cin_multi(pressure, temperature, dewpoint, parcels, want=None, moist=None, lifted_index_at=None, fused=False, **kwargs):
     """Several parcels of one grid in ONE call (xp_cape_cin_multi): `parcels` is a sequence of names or (name, depth)
     pairs out of 'surface', 'most_unstable', 'mixed_layer' -- e.g. [('most_unstable', 300), ('mixed_layer', 100)] for
     BASELINE config 5, [('most_unstable', 250), ('mixed_layer', 100), ('mixed_layer', 50)] for conv_properties
-    (pf.py:1984-2006).  Returns one dict per parcel, bit-identical to what cape_cin_columns() returns for it; with
-    moist='family' and dewpoint input the parcels share one pass over the grid."""
+    (pf.py:1984-2006).  Returns one dict per parcel, bit-identical to what cape_cin_columns() returns for it.
+    fused=True (XP_OPT_FUSE_PARCELS; moist='family', two parcels): one pass over the grid for both -- same numbers,
+    measured slower than a pass per parcel on MI355X, hence opt-in."""
     (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
     assert p.shape == t.shape == td.shape, 'pressure, temperature, dewpoint must share a shape'
     nlev, ncol, hshape = _vert_shape(p)
     lib = L.init(_device_of(p))
     o = _opts(moist=moist or _DEFAULT['moist'], **kwargs)
+    o.flags = L.OPT_FUSE_PARCELS if fused else 0
     specs = []
     for pc in parcels:
         name, depth = (pc, None) if isinstance(pc, str) else (pc[0], pc[1])
