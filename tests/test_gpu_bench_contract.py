@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                          '--ny', '64', '--cpu-sample', '4096'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          '--ny', '64', '--cpu-sample', '4096', '--leg-scale', '256'], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
@@ -30,6 +30,21 @@ def test_bench_json_contract():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert d['value'] > 1e6
+    # the other BASELINE configs as legs on the driver's clock (reduced by --leg-scale here), each with its oracle check
+    for k in ('c3', 'c4_share', 'c5_share'):
+        assert k in d and 'error' not in d[k], (k, d.get(k))
+    for m in ('family', 'exact'):
+        c3 = d['c3'][m]
+        assert c3['kernel_ms'] > 0 and 0 < c3['frac'] < 1 and c3['check']['indices_identical'] and c3['check']['profile_nan_pattern_identical']
+        assert c3['check']['columns'] >= 4000 and c3['check']['cape_maxdiff'] < 5e-3 and c3['check']['profile_T_maxdiff'] < 1e-4
+    assert d['c4_share']['kernel_ms'] > 0 and d['c4_share']['check']['indices_identical'] and d['c4_share']['check']['columns'] >= 4000
+    c5 = d['c5_share']
+    for pc in ('most_unstable', 'mixed_layer'):
+        assert c5[pc]['kernel_ms'] > 0 and c5[pc]['check']['indices_identical'] and c5[pc]['check']['cape_maxdiff'] < 5e-3
+    assert abs(c5['step_ms'] - c5['most_unstable']['kernel_ms'] - c5['mixed_layer']['kernel_ms']) < 1e-9
+    assert c5['fused_step']['bitwise_equal_to_two_passes'] is True and c5['fused_step']['kernel_ms'] > 0
+    n = d['cpu_baseline_numpy']
+    assert n['kind'] == 'port' and n['cores'] == 1 and n['value'] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_rehearsal():
@@ -38,7 +53,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     env = dict(os.environ, XPARCEL_BENCH_SINGLE_DEVICE='1', XPARCEL_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29517', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--ny', '64',
-           '--no-cpu']
+           '--no-cpu', '--leg-scale', '64']
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -46,6 +61,10 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and 'cpu_baseline' not in d
     assert d['config']['columns_this_rank'] == 64 * 1024 and d['config']['columns_total'] == 2 * 64 * 1024
+    # the fixed-grid (strong-scaling) curve of SURVEY 8(e) rides along with the driver's command line as a leg
+    s4 = d['strong_c4']
+    assert s4['scaling'] == 'strong' and s4['n_gpus'] == 2 and s4['columns_total'] == 128 * 8192 and s4['columns_this_rank'] == 64 * 8192
+    assert s4['value'] > 0 and s4['check']['max_cape'] > 100.0
 
 
 def test_bench_fixed_grid_configs_two_ranks_rehearsal():
