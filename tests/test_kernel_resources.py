@@ -75,11 +75,28 @@ def test_surface_kernel_keeps_four_waves_per_simd(tmp_path):
 @needs_hipcc
 def test_family_kernels_fit_one_workgroup_per_cu(tmp_path):
     rec = _resources(tmp_path, 2)
-    # what xp_cape_tu.hip dispatches in family mode: the generic instantiation for every parcel (the default-options /
-    # CAPE-CIN-only specialisations come out of the register allocator at 128 VGPRs + 70..180 B of scratch here)
-    # -- each as an ordinary launch and with persistent wavefronts (grids of 4 Mi columns and more)
-    for (pm, deflt, lean), persist in itertools.product(((0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0)), (0, 1)):
+    # what xp_cape_tu.hip dispatches in family mode: the default-options + CAPE/CIN-only specialisation (DEF + LEAN) when
+    # the caller asks for no more, the generic instantiation otherwise (DEF alone spills 40-55 VGPRs for the searching
+    # parcels at the 128-VGPR cap) -- each as an ordinary launch and with persistent wavefronts
+    for (pm, deflt, lean), persist in itertools.product(((0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0),
+                                                         (0, 1, 1), (1, 1, 1), (2, 1, 1), (3, 1, 1)), (0, 1)):
         r = _pick(rec, pm, 0, 2, 0, deflt, lean, persist)
         assert r['vgprs'] <= 128 and r['occupancy'] >= 4, r
         assert r['lds'] <= 160 * 1024, r
         assert r['spills'] == 0 and r['scratch'] <= 64, r    # no spill in the kernel; the scratch is the frames of the out-of-line slow paths
+
+
+@needs_hipcc
+def test_fused_parcels_kernel_fits_one_workgroup_per_cu(tmp_path):
+    """csrc/xp_multi.hpp, two parcels per thread: 512-thread workgroups (two wavefronts per SIMD, up to 256 VGPRs), LDS
+    = tables + 2 x 12 slot fields x 512 threads within the CU's 160 KB, no VGPR spill."""
+    src = os.path.join(ROOT, 'xarray_parcel_amd', 'csrc', 'xp_multi_tu.hip')
+    cmd = ([HIPCC if os.path.exists(HIPCC) else 'hipcc'] + [f for f in _lib.HIPCC_FLAGS if f != '-fPIC'] +
+           ['-S', '--cuda-device-only', '-DXP_TU_T=float', '-DXP_MULTI_NP=2'] + _lib.MULTI_FLAGS[2] +
+           ['-Rpass-analysis=kernel-resource-usage', '-o', str(tmp_path / 'mt.s'), src])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    vg = [int(x) for x in re.findall(r' VGPRs: (\d+)', out.stderr)]
+    lds = [int(x) for x in re.findall(r'LDS Size \[bytes/block\]: (\d+)', out.stderr)]
+    sp = [int(x) for x in re.findall(r'VGPRs Spill: (\d+)', out.stderr)]
+    assert len(vg) == 2 and max(vg) <= 256 and max(lds) <= 160 * 1024 and max(sp) == 0, (vg, lds, sp)

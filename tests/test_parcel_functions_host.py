@@ -136,8 +136,11 @@ def test_default_moist_mode_on_gpu():
     ode, _ = pf.surface_based_cape_cin(p, t, td, moist='exact')
     assert float(res.cape.values) == float(tab.cape.values)
     assert 1e-3 < abs(float(res.cape.values) - float(ode.cape.values)) < 40.0     # demo.ipynb:320-329: up to 33 J/kg
-    ml = pf.moist_lapse(_da([1000., 900., 800.]), np.array([293.0]))
-    assert np.allclose(np.asarray(ml.values).ravel(), [293.0, 288.7, 284.0], atol=0.3)
+    lev = _da([1000., 900., 800.])
+    ml = np.asarray(pf.moist_lapse(lev, np.array([293.0])).values).ravel()
+    assert np.array_equal(ml, np.asarray(pf.moist_lapse(lev, np.array([293.0]), moist='table').values).ravel())
+    ode = np.asarray(pf.moist_lapse(lev, np.array([293.0]), moist='exact').values).ravel()
+    assert 1e-4 < np.max(np.abs(ml - ode)) < 0.08                                 # the table's error (demo.ipynb:252: 0.037 K; :322: 0.077 K)
 
 
 @pytest.mark.gpu

@@ -35,16 +35,19 @@ template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeAr
         return;
     }
     if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a); return; }
-    // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations -- for the RK4 and lookup-table modes.  The family
-    // kernels sit at the 128-VGPR cap of their 1024-thread workgroups, and there the specialised instantiations come out
-    // of the register allocator WORSE than the generic one (measured, DESIGN.md 7: 128 VGPRs + 72..184 B of scratch
-    // against 122..128 and none; 7 % and more slower), so family mode always takes the generic kernel.
+    // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations: the reference's default option set as compile-time
+    // constants, and -- when the caller wants neither LFC / EL temperatures nor interval indices (the bench, a multi-GPU
+    // gather, the product bundle) -- no tracking of them.  The RK4 and lookup-table modes take both; the family kernels
+    // sit at the 128-VGPR cap of their 1024-thread workgroups and take only the combination DEF + LEAN, which comes out
+    // of the register allocator without a spill for every parcel (121-128 VGPRs; round 2's code base spilled here and
+    // always took the generic kernel) and runs 2.5-5 % faster than the generic one (same-box A/B); DEF
+    // alone still spills for the searching parcels (40-55 VGPRs) and stays with the generic kernel.
     // tests/test_kernel_resources.py watches the numbers this rule rests on.
-    constexpr bool SPECIALISE = MODE != 2;
-    if constexpr (SPECIALISE) {
-        const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
-        if (a.vtc && a.pos_neg && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a); return; }
-        if (a.vtc && a.pos_neg) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false, PERSIST>), gr, bl, 0, s, a); return; }
+    const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
+    const bool dflt = a.vtc && a.pos_neg && a.log_interp;                           // the reference's defaults (pf.py:1396, 1293)
+    if (dflt && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a); return; }
+    if constexpr (MODE != 2) {
+        if (dflt) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, false, PERSIST>), gr, bl, 0, s, a); return; }
     }
     hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a);
 }

@@ -320,9 +320,10 @@ XP_DEV Lcl lcl(double p_start, double t, double td) {
     if (fabs(p - p_start) <= 1e-8 + 1e-5 * fabs(p_start)) p = p_start;    // np.isclose snap (MetPy issue #1187)
     r.p = p;
     r.t = dewpoint_fast(p * fdiv(w, EPS + w));
-    r.tv = virt_ref(r.t, r.t, p);                                          // RH = 1 at the LCL (pf.py:653-657)
-    // saturated parcels (LCL snapped onto the parcel level) also take the reference spelling: the sign of T_lcl - T
-    // there is rounding noise of exactly those expressions (see the on-LCL handling in k_cape_cin)
+    // RH = 1 at the LCL (pf.py:653-657).  Fast forms (3e-16 relative; the library-math spelling cost ~150 instructions per
+    // column); saturated parcels (LCL snapped onto the parcel level) take the reference spelling below, all of it: the sign
+    // of T_lcl - T there is rounding noise of exactly those expressions (see the on-LCL handling in k_cape_cin)
+    r.tv = virt(r.t, mix_of_e(sat_vapor_pressure(r.t), p));
     bool ref_path = !sane || (p == p_start);
     if (__builtin_amdgcn_ballot_w64(ref_path) != 0ull && ref_path) r = lcl_reference(p_start, t, td);
     return r;

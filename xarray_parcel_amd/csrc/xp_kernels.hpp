@@ -216,7 +216,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // MODE: 0 = exact by RK4, 1 = reference lookup tables, 2 = exact by the adiabat family (columns it cannot serve are
 // flagged and redone by a MODE 0 launch with only_flagged set).
 // HUM: the moisture view holds specific humidity (XP_HUM_SPECIFIC).
-// DEF: the reference's default option set, virtual-temperature correction on and sign-filtered sums (pf.py:1396, 1293),
+// DEF: the reference's default option set -- virtual-temperature correction on, LCL environment interpolated in ln p, sign-filtered sums (pf.py:1396, 1293) --
 // as compile-time constants: the selects and scalar registers the run-time switches cost in the level loop go away.
 // Instantiated for the dewpoint-input kernels of modes 0 / 1; family mode and every other combination take DEF = false
 // (xp_cape_tu.hip has the dispatch rule and why).
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         pc = select_ml<T, HUM>(a, c, es, a.depth);
     }
 
-    const bool vtc = DEF || (a.vtc != 0), pos_neg = DEF || (a.pos_neg != 0);
+    const bool vtc = DEF || (a.vtc != 0), pos_neg = DEF || (a.pos_neg != 0), log_interp = DEF || (a.log_interp != 0);
     const bool need_w = vtc || PROFILE;
     const Lcl l = lcl(pc.p, pc.t, pc.td);
     int status = l.not_converged ? 2 : 0;
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // environment at the LCL: bracketing-level interpolation in ln p or p (pf.py:897-906, 1758-1811) between the last
     // valid level at or below the LCL (the br slots) and the first level above it
     auto lcl_environment = [&](double pa, double xa, double ta, double tda, double &te, double &tde) __attribute__((always_inline)) {
-        double at = a.log_interp ? x_lcl : l.p;
+        double at = log_interp ? x_lcl : l.p;
         const double pb = br[SL_BR_P * SLOT_STRIDE], xb = br[SL_BR_X * SLOT_STRIDE], tb_ = br[SL_BR_T * SLOT_STRIDE], tdb = br[SL_BR_TD * SLOT_STRIDE];
-        double cb = a.log_interp ? xb : pb, ca = a.log_interp ? xa : pa;
+        double cb = log_interp ? xb : pb, ca = log_interp ? xa : pa;
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
         te = interp_rule(tb_, ta2, at, cb, ca); tde = interp_rule(tdb, tda2, at, cb, ca);
