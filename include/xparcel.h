@@ -281,6 +281,31 @@ int xp_crossing_level(const xp_view *x, const xp_view *a, double value, void *ou
    the layout of `temperature`.  (virtual_temperature, pf.py:782-804, is T (1 + 0.608 w): plain arithmetic in the mirror.) */
 int xp_mixing_ratio(const xp_view *temperature, const xp_view *dewpoint, const xp_view *pressure, void *out, void *stream);
 
+/* pf.py:1951-2100 conv_properties, the reference's product bundle, in ONE call: the q -> dewpoint front step and the NaN mask,
+   most-unstable (250 hPa), 100 hPa and 50 hPa mixed-layer CAPE / CIN with their lifted indices (pf.py:1722) out of the same
+   passes, the three deep convective indices (pf.py:1830), the 700-500 hPa lapse rate (pf.py:2102), the 500 hPa temperature
+   (pf.py:2193), freezing and melting level (pf.py:2137, 2160 with the 1/3-rule wet bulb), the 0-6 km shear (pf.py:2216) and the
+   mixing ratio of the most-unstable parcel (pf.py:2053-2059); points with a NaN anywhere in pressure / temperature / humidity /
+   dewpoint are blanked unless ignore_nans (pf.py:2097-2098).  Everything that is not parcel lifting is one pass over the four
+   grids plus one per-point kernel (csrc/xp_bundle.hpp); scratch (the dewpoint array, per-point temporaries) is stream-ordered
+   and internal.  The four (nlev, ncol) views share dtype and mem; the wind views are (nwind, ncol) on their own vertical;
+   surface winds and every output are ncol values of that dtype in that mem (positive_shear: int32 0 / 1); NULL outputs are
+   skipped.  opts: moist_mode and the CAPE / CIN options of xp_cape_cin (humidity is ignored: the input IS specific humidity). */
+typedef struct {
+    const xp_view *pressure, *temperature, *specific_humidity, *height_asl;
+    const xp_view *wind_u, *wind_v, *wind_height_above_surface;
+    const void *surface_wind_u, *surface_wind_v;
+} xp_conv_in;
+typedef struct {
+    void *mu_cape, *mu_cin, *mu_mixing_ratio, *mu_lifted_index, *mu_dci;
+    void *mixed_100_cape, *mixed_100_cin, *mixed_100_lifted_index, *mixed_100_dci;
+    void *mixed_50_cape, *mixed_50_cin, *mixed_50_lifted_index, *mixed_50_dci;
+    void *lapse_rate_700_500, *temp_500, *freezing_level, *melting_level;
+    void *shear_u, *shear_v, *shear_magnitude;
+    int32_t *positive_shear;
+} xp_conv_out;
+int xp_conv_properties(const xp_conv_in *in, const xp_opts *opts, int32_t ignore_nans, xp_conv_out *out, void *stream);
+
 const char *xp_last_error(void);
 
 #ifdef __cplusplus

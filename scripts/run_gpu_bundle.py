@@ -33,6 +33,8 @@ def parcels(want):
 
 
 out = {'grid': [nlev, ncol], 'conv_properties_ms': timed(lambda: xa.conv_properties(d)),
+       'conv_properties_family_ms': timed(lambda: xa.conv_properties(d, moist='family')),
+       'conv_properties_composed_ms': timed(lambda: xa.conv_properties_composed(d)),
        'three_parcel_passes_all_six_arrays_ms': timed(lambda: parcels(True)),
        'three_parcel_passes_lifted_index_arrays_ms': timed(lambda: parcels(xa.LIFTED_INDEX_VARS)),
        'three_parcel_passes_no_profile_ms': timed(lambda: parcels(False))}

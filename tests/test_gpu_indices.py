@@ -211,6 +211,41 @@ def _bundle_inputs(nlev=40, ncol=48, seed=51, nan_fraction=0.06):
             'wind_height_above_surface': wh, 'surface_wind_u': rng.normal(2, 2, ncol), 'surface_wind_v': rng.normal(0, 2, ncol)}
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_conv_properties_one_call_equals_the_composition(xa, dtype):
+    """xp_conv_properties (one pass over the four grids + three parcel passes + one per-point kernel) against the
+    composition of stand-alone calls and array arithmetic it replaces: identical NaN pattern, values to rounding of the
+    per-point arithmetic (the parcel results and the interpolated values are bit-identical); host arrays and device
+    tensors; ignore_nans."""
+    import torch
+    d = {k: np.asarray(v, dtype=dtype) for k, v in _bundle_inputs(nlev=33, ncol=3000, seed=7).items()}
+    dd = {k: torch.as_tensor(v).cuda() for k, v in d.items()}          # (the composition keeps the data's type only for device tensors)
+    rtol = 1e-12 if dtype == np.float64 else 2e-6
+    for moist in ('exact', 'family'):
+        for ignore in (False, True):
+            ref = xa.conv_properties_composed(dd, ignore_nans=ignore, moist=moist)
+            got = xa.conv_properties(d, ignore_nans=ignore, moist=moist)
+            assert set(got) == set(ref)
+            for k in ref:
+                a, b = np.asarray(got[k]), ref[k].cpu().numpy()
+                if k == 'positive_shear':
+                    assert a.dtype == bool and np.array_equal(a, b.astype(bool)), (moist, ignore, k)
+                    continue
+                assert a.dtype == dtype and np.array_equal(np.isnan(a), np.isnan(b)), (moist, ignore, k)
+                ok = ~np.isnan(b)
+                err = np.abs(a[ok].astype(np.float64) - b[ok].astype(np.float64))
+                # (float32: the composition forms differences of ~300 K numbers in float32 -- an ulp there is 3e-5 K --, the
+                # per-point kernel in float64)
+                atol = 0.0 if dtype == np.float64 else 3e-4
+                assert np.all(err <= atol + rtol * np.maximum(1.0, np.abs(b[ok]))), (moist, ignore, k, float(err.max()))
+                if k.endswith('_cape') or k.endswith('_cin') or k in ('temp_500', 'freezing_level', 'melting_level'):
+                    assert np.array_equal(a[ok], b[ok]), (moist, ignore, k)
+    dev = xa.conv_properties(dd)
+    host = xa.conv_properties(d)
+    for k in host:
+        assert np.array_equal(dev[k].cpu().numpy(), host[k], equal_nan=True), k
+
+
 def test_conv_properties_and_storm_proxies_vs_oracle(xa):
     """The reference's product bundle (pf.py:1951 conv_properties, pf.py:2323 storm_proxies) as compositions of the
     device calls, against the same compositions of the oracle, column by column."""

@@ -23,7 +23,7 @@ ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_cape_cin_multi', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
            'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_interp_levels', 'xp_dewpoint_from_specific_humidity',
-           'xp_crossing_level', 'xp_mixing_ratio', 'xp_last_error')
+           'xp_crossing_level', 'xp_mixing_ratio', 'xp_conv_properties', 'xp_last_error')
 
 
 class View(C.Structure):
@@ -61,6 +61,21 @@ class ProfileOut(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in PROFILE_VARS] +
                 [('dtype', C.c_int32), ('mem', C.c_int32), ('nlev_out', C.c_int64), ('lev_stride', C.c_int64),
                  ('col_stride', C.c_int64), ('lifted_index', C.c_void_p), ('lifted_index_pressure', C.c_double)])
+
+
+CONV_IN_VIEWS = ('pressure', 'temperature', 'specific_humidity', 'height_asl', 'wind_u', 'wind_v', 'wind_height_above_surface')
+CONV_OUT = ('mu_cape', 'mu_cin', 'mu_mixing_ratio', 'mu_lifted_index', 'mu_dci', 'mixed_100_cape', 'mixed_100_cin',
+            'mixed_100_lifted_index', 'mixed_100_dci', 'mixed_50_cape', 'mixed_50_cin', 'mixed_50_lifted_index', 'mixed_50_dci',
+            'lapse_rate_700_500', 'temp_500', 'freezing_level', 'melting_level', 'shear_u', 'shear_v', 'shear_magnitude',
+            'positive_shear')
+
+
+class ConvIn(C.Structure):
+    _fields_ = [(k, C.POINTER(View)) for k in CONV_IN_VIEWS] + [('surface_wind_u', C.c_void_p), ('surface_wind_v', C.c_void_p)]
+
+
+class ConvOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in CONV_OUT]
 
 
 class Tables(C.Structure):

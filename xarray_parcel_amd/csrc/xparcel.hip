@@ -14,6 +14,7 @@
 #include "../../include/xparcel.h"
 #include "xp_kernels.hpp"
 #include "xp_multi.hpp"
+#include "xp_bundle.hpp"
 
 namespace {
 
@@ -584,6 +585,122 @@ int xp_cape_cin_multi(const xp_view *p, const xp_view *t, const xp_view *td, int
         if (f64) xp::launch_cape_mode<double, 0>(b, m.mode[i], false, st.s);
         else xp::launch_cape_mode<float, 0>(b, m.mode[i], false, st.s);
     }
+    return st.finish();
+}
+
+int xp_conv_properties(const xp_conv_in *in, const xp_opts *o, int32_t ignore_nans, xp_conv_out *out, void *stream) {
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!in || !out) return fail(XP_E_ARG, "xp_conv_properties: null argument");
+    const xp_view *p = in->pressure, *t = in->temperature, *q = in->specific_humidity, *z = in->height_asl;
+    const xp_view *wu = in->wind_u, *wv = in->wind_v, *wh = in->wind_height_above_surface;
+    if ((rc = check_view(p, "pressure")) || (rc = check_view(t, "temperature")) || (rc = check_view(q, "specific_humidity")) ||
+        (rc = check_view(z, "height_asl")) || (rc = same_shape(p, t, "pressure/temperature")) ||
+        (rc = same_shape(p, q, "pressure/specific_humidity")) || (rc = same_shape(p, z, "pressure/height_asl"))) return rc;
+    if ((rc = check_view(wu, "wind_u")) || (rc = check_view(wv, "wind_v")) || (rc = check_view(wh, "wind_height_above_surface")) ||
+        (rc = same_shape(wu, wv, "wind_u/wind_v")) || (rc = same_shape(wu, wh, "wind_u/wind_height_above_surface"))) return rc;
+    if (wu->ncol != p->ncol || wu->dtype != p->dtype || wu->mem != p->mem || t->mem != p->mem || q->mem != p->mem || z->mem != p->mem)
+        return fail(XP_E_ARG, "xp_conv_properties: the views must agree in columns, dtype and mem");
+    if (!in->surface_wind_u || !in->surface_wind_v) return fail(XP_E_ARG, "xp_conv_properties: null surface wind");
+    Stager st(stream);
+    const int64_t nlev = p->nlev, ncol = p->ncol;
+    const size_t es = esize(p->dtype), cb = (size_t)ncol * es;
+    const int mem = p->mem;
+    if (ncol == 0) return XP_OK;
+    // inputs on the device (host views are dense by contract: staged as they are)
+    xp_view dv[7];
+    const xp_view *src[7] = {p, t, q, z, wu, wv, wh};
+    for (int i = 0; i < 7; ++i) {
+        dv[i] = *src[i];
+        const void *d;
+        if ((rc = st.in(src[i]->data, (size_t)src[i]->nlev * (size_t)ncol * es, mem, &d))) return rc;
+        dv[i].data = d; dv[i].mem = XP_MEM_DEVICE;
+    }
+    const void *sfu, *sfv;
+    if ((rc = st.in(in->surface_wind_u, cb, mem, &sfu)) || (rc = st.in(in->surface_wind_v, cb, mem, &sfv))) return rc;
+    // scratch: the dewpoint grid and per-point temporaries
+    auto scratch = [&](size_t bytes, void **ptr) -> int {
+        HIP_TRY(hipMallocAsync(ptr, bytes ? bytes : 1, st.s));
+        st.scratch.push_back(*ptr);
+        return 0;
+    };
+    void *td = nullptr, *tmp = nullptr, *valid = nullptr;
+    enum { T850, T700, T500, TD850, Z700, Z500, HIU, HIV, MUP, MUTD, NTMP };
+    if ((rc = scratch((size_t)nlev * cb, &td)) || (rc = scratch((size_t)NTMP * cb, &tmp)) || (rc = scratch((size_t)ncol * 4, &valid))) return rc;
+    auto tp = [&](int i) { return (void *)((char *)tmp + (size_t)i * cb); };
+    // outputs: the caller's buffers when they live on the device, staged otherwise; results that are also inputs of the
+    // per-point kernel need a buffer even when the caller does not want them
+    void *o_[21];
+    void *const want[21] = {out->mu_cape, out->mu_cin, out->mu_mixing_ratio, out->mu_lifted_index, out->mu_dci,
+                            out->mixed_100_cape, out->mixed_100_cin, out->mixed_100_lifted_index, out->mixed_100_dci,
+                            out->mixed_50_cape, out->mixed_50_cin, out->mixed_50_lifted_index, out->mixed_50_dci,
+                            out->lapse_rate_700_500, out->temp_500, out->freezing_level, out->melting_level,
+                            out->shear_u, out->shear_v, out->shear_magnitude, (void *)out->positive_shear};
+    for (int i = 0; i < 21; ++i) {
+        const size_t b = i == 20 ? (size_t)ncol * 4 : cb;
+        if (want[i]) { if ((rc = st.out(want[i], b, mem, &o_[i]))) return rc; }
+        else if ((rc = scratch(b, &o_[i]))) return rc;
+    }
+    enum { O_MU_CAPE, O_MU_CIN, O_MU_W, O_MU_LI, O_MU_DCI, O_M1_CAPE, O_M1_CIN, O_M1_LI, O_M1_DCI, O_M5_CAPE, O_M5_CIN, O_M5_LI, O_M5_DCI,
+           O_LAPSE, O_T500, O_FRZ, O_MLT, O_SHU, O_SHV, O_SHM, O_POS };
+    // 1. one pass over the four grids
+    xp::ConvColumnsArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.p = {dv[0].data, dv[0].lev_stride, dv[0].col_stride}; ca.t = {dv[1].data, dv[1].lev_stride, dv[1].col_stride};
+    ca.q = {dv[2].data, dv[2].lev_stride, dv[2].col_stride}; ca.z = {dv[3].data, dv[3].lev_stride, dv[3].col_stride};
+    ca.nlev = nlev; ca.ncol = ncol; ca.td = td;
+    ca.t850 = tp(T850); ca.t700 = tp(T700); ca.t500 = tp(T500); ca.td850 = tp(TD850); ca.z700 = tp(Z700); ca.z500 = tp(Z500);
+    ca.freezing = o_[O_FRZ]; ca.melting = o_[O_MLT]; ca.valid = (int32_t *)valid;
+    if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_conv_columns<double>), dim3(blocks(ncol)), dim3(256), 0, st.s, ca);
+    else hipLaunchKernelGGL((xp::k_conv_columns<float>), dim3(blocks(ncol)), dim3(256), 0, st.s, ca);
+    // 2. the three parcels (pf.py:1984-2006), lifted index out of the same passes
+    xp_view tdv = dv[0];
+    tdv.data = td; tdv.lev_stride = ncol; tdv.col_stride = 1;
+    xp_opts oo;
+    if (o) oo = *o; else { memset(&oo, 0, sizeof(oo)); oo.virtual_temperature_correction = 1; oo.lcl_interp = XP_LCL_INTERP_LOG; oo.pos_cape_neg_cin = 1; oo.compute = XP_F64; }
+    oo.humidity = XP_HUM_DEWPOINT;
+    const struct { int mode; double depth; int cape, cin, li; } pc[3] = {{XP_PARCEL_MOST_UNSTABLE, 250.0, O_MU_CAPE, O_MU_CIN, O_MU_LI},
+                                                                        {XP_PARCEL_MIXED_LAYER, 100.0, O_M1_CAPE, O_M1_CIN, O_M1_LI},
+                                                                        {XP_PARCEL_MIXED_LAYER, 50.0, O_M5_CAPE, O_M5_CIN, O_M5_LI}};
+    for (int i = 0; i < 3; ++i) {
+        xp_parcel par;
+        memset(&par, 0, sizeof(par));
+        par.mode = pc[i].mode; par.depth = pc[i].depth;
+        xp_scalars_out so;
+        memset(&so, 0, sizeof(so));
+        so.dtype = p->dtype; so.mem = XP_MEM_DEVICE; so.cape = o_[pc[i].cape]; so.cin = o_[pc[i].cin];
+        if (i == 0) { so.parcel_pressure = tp(MUP); so.parcel_dewpoint = tp(MUTD); }
+        xp_profile_out po;
+        memset(&po, 0, sizeof(po));
+        po.dtype = p->dtype; po.mem = XP_MEM_DEVICE; po.nlev_out = nlev + 1; po.lev_stride = ncol; po.col_stride = 1;
+        po.lifted_index = o_[pc[i].li]; po.lifted_index_pressure = 500.0;
+        if ((rc = xp_cape_cin(&dv[0], &dv[1], &tdv, &par, &oo, &so, &po, stream))) return rc;
+    }
+    // 3. wind at 6000 m above the surface (pf.py:2240-2243: linear interpolation in height)
+    {
+        const xp_view *vars[2] = {&dv[4], &dv[5]};
+        const double at6 = 6000.0;
+        void *outs[2] = {tp(HIU), tp(HIV)};
+        if ((rc = xp_interp_levels(&dv[6], 2, vars, 1, &at6, 0, outs, stream))) return rc;
+    }
+    // 4. per point
+    xp::ConvFinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.ncol = ncol; fa.ignore_nans = ignore_nans != 0;
+    fa.mu_p = tp(MUP); fa.mu_td = tp(MUTD);
+    fa.li[0] = o_[O_MU_LI]; fa.li[1] = o_[O_M1_LI]; fa.li[2] = o_[O_M5_LI];
+    fa.t850 = tp(T850); fa.t700 = tp(T700); fa.t500 = tp(T500); fa.td850 = tp(TD850); fa.z700 = tp(Z700); fa.z500 = tp(Z500);
+    fa.hi_u = tp(HIU); fa.hi_v = tp(HIV); fa.sfc_u = sfu; fa.sfc_v = sfv; fa.valid = (const int32_t *)valid;
+    fa.cape[0] = o_[O_MU_CAPE]; fa.cape[1] = o_[O_M1_CAPE]; fa.cape[2] = o_[O_M5_CAPE];
+    fa.cin[0] = o_[O_MU_CIN]; fa.cin[1] = o_[O_M1_CIN]; fa.cin[2] = o_[O_M5_CIN];
+    fa.li_out[0] = o_[O_MU_LI]; fa.li_out[1] = o_[O_M1_LI]; fa.li_out[2] = o_[O_M5_LI];
+    fa.freezing = o_[O_FRZ]; fa.melting = o_[O_MLT];
+    fa.mu_mixing_ratio = o_[O_MU_W]; fa.dci[0] = o_[O_MU_DCI]; fa.dci[1] = o_[O_M1_DCI]; fa.dci[2] = o_[O_M5_DCI];
+    fa.lapse = o_[O_LAPSE]; fa.temp_500 = o_[O_T500]; fa.shear_u = o_[O_SHU]; fa.shear_v = o_[O_SHV]; fa.shear_mag = o_[O_SHM];
+    fa.positive_shear = (int32_t *)o_[O_POS];
+    if (p->dtype == XP_F64) hipLaunchKernelGGL((xp::k_conv_finish<double>), dim3(blocks(ncol)), dim3(256), 0, st.s, fa);
+    else hipLaunchKernelGGL((xp::k_conv_finish<float>), dim3(blocks(ncol)), dim3(256), 0, st.s, fa);
     return st.finish();
 }
 

@@ -632,10 +632,41 @@ def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh
 
 
 def conv_properties(dat, ignore_nans=False, moist=None):
-    """pf.py:1951: the reference's convective-property bundle for a grid.  `dat`: mapping with pressure [hPa],
-    temperature [K], specific_humidity [kg/kg], height_asl [m] (nlev, ...), wind_u, wind_v,
-    wind_height_above_surface (nwind, ...), surface_wind_u, surface_wind_v (...).  Returns a dict of per-column
-    arrays with the reference's variable names."""
+    """pf.py:1951: the reference's convective-property bundle for a grid, ONE library call (xp_conv_properties): the
+    q -> dewpoint step, the NaN mask, the fixed-level interpolations and the freezing / melting levels are one pass over
+    the four grids, the three parcels' CAPE / CIN / lifted index three more, the rest one per-point kernel -- no array
+    arithmetic on this side.  `dat`: mapping with pressure [hPa], temperature [K], specific_humidity [kg/kg],
+    height_asl [m] (nlev, ...), wind_u, wind_v, wind_height_above_surface (nwind, ...), surface_wind_u, surface_wind_v
+    (...): NumPy arrays (staged through the library) or torch CUDA tensors (in place).  Returns a dict of per-column
+    arrays with the reference's variable names (positive_shear: bool)."""
+    order = L.CONV_IN_VIEWS + ('surface_wind_u', 'surface_wind_v')
+    hs, dt, dev = _common(*[dat[k] for k in order])
+    h = dict(zip(order, hs))
+    p = h['pressure']
+    assert all(h[k].shape == p.shape for k in ('temperature', 'specific_humidity', 'height_asl')), 'pressure, temperature, specific_humidity, height_asl must share a shape'
+    nlev, ncol, hshape = _vert_shape(p)
+    wu = h['wind_u']
+    assert wu.shape == h['wind_v'].shape == h['wind_height_above_surface'].shape and tuple(wu.shape[1:]) == hshape, 'wind arrays must be (nwind, ...) over the same points'
+    nwind = wu.shape[0]
+    lib = L.init(_device_of(p))
+    views = {k: _view(h[k], nlev if k in L.CONV_IN_VIEWS[:4] else nwind, ncol) for k in L.CONV_IN_VIEWS}
+    ci = L.ConvIn(*[C.pointer(views[k]) for k in L.CONV_IN_VIEWS], h['surface_wind_u'].ptr, h['surface_wind_v'].ptr)
+    assert int(np.prod(h['surface_wind_u'].shape)) == ncol and int(np.prod(h['surface_wind_v'].shape)) == ncol
+    co, out = L.ConvOut(), {}
+    for k in L.CONV_OUT:
+        arr, ptr = _alloc((ncol,), np.int32 if k == 'positive_shear' else dt, dev, p)
+        setattr(co, k, ptr)
+        out[k] = arr
+    o = _opts(moist=moist or _DEFAULT['moist'])
+    L.check(lib.xp_conv_properties(C.byref(ci), C.byref(o), C.c_int32(int(bool(ignore_nans))), C.byref(co), _stream(dev)))
+    res = {k: v.reshape(hshape) for k, v in out.items()}
+    res['positive_shear'] = res['positive_shear'] != 0
+    return res
+
+
+def conv_properties_composed(dat, ignore_nans=False, moist=None):
+    """The same bundle as a composition of the stand-alone calls plus array arithmetic (what conv_properties() was before
+    xp_conv_properties existed): kept as the cross-check of the fused call (tests/test_gpu_indices.py)."""
     host_in = not any(_is_torch(v) for v in dat.values())
     if host_in and torch is not None and torch.cuda.is_available():
         # one upload; the ~25 kernel launches of the bundle then work on device-resident data
