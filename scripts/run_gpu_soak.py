@@ -9,7 +9,10 @@ from xarray_parcel_amd import numpy_api as xa, synth
 tp.xa = xa
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 seeds = range(100, 100 + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
-variant = sys.argv[3] if len(sys.argv) > 3 else 'exact'        # exact | family | table | specific (q input, fused conversion)
+variant = sys.argv[3] if len(sys.argv) > 3 else 'exact'        # exact | family | table | specific (q input, fused conversion) | fused (xp_cape_cin_multi, one pass for two parcels)
+fused = variant == 'fused'
+if fused:
+    variant = 'family'
 if variant == 'family':
     xa.set_family_table(co.family_table())                     # both sides interpolate the oracle's table
 if variant == 'table':
@@ -35,6 +38,16 @@ for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100)
         got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, **kw)
         ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if variant == 'exact' else variant, **kw)
     n += 1
+    if fused and parcel != 'surface':             # the pair (this parcel, surface) in ONE pass against the separate calls, bit for bit
+        try:
+            pair = xa.cape_cin_multi(p, t, td, [(parcel, None), ('surface', None)], moist='family', fused=True, **kw)
+            sfc = xa.cape_cin_columns(p, t, td, parcel='surface', moist='family', **kw)
+            for g_, r_ in ((pair[0], got), (pair[1], sfc)):
+                for k in r_:
+                    assert np.array_equal(np.asarray(g_[k]), np.asarray(r_[k]), equal_nan=True), ('fused pass differs', k)
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH (fused)', seed, nlev, parcel, mode, dtype.__name__, str(e)[:300], flush=True)
     try:
         if mode == 0 and variant != 'specific':      # the CAPE / CIN-only (LEAN) instantiation: bit-identical to the all-outputs kernel
             lean = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, want=('cape', 'cin', 'lfc_pressure', 'el_pressure', 'status'))
