@@ -127,6 +127,17 @@ __device__ __attribute__((noinline)) double crossing_x_ref(double y, double yp, 
     return (a - b) / (y - yp);
 }
 
+// One s_waitcnt lgkmcnt(0) for a group of LDS reads that has just been requested, pinned in place: left alone the compiler
+// waits for every value separately, right before the instruction that consumes it (lgkmcnt(4), (3), (2) ... between the
+// steps of a Horner evaluation) -- four or five more instructions per group, and an instruction of ANY kind costs a
+// wavefront an issue slot (a wavefront issues at most one instruction per ~4-5 cycles; with four wavefronts per SIMD
+// that, not the fp64 pipe, is what the kernel runs into: scripts/dbg/fma_lat.hip).  vmcnt / expcnt untouched.
+XP_DEV void lds_wait_all() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- e_s(T) from an LDS-resident table ---------------------------------------------------------------
 // The per-level path needs e_s six times per level (environment T and Td, three RK4 stages, the parcel).
 // exp + reciprocal cost ~27 fp64 instructions each; instead every workgroup stages a table into LDS:
@@ -136,7 +147,7 @@ __device__ __attribute__((noinline)) double crossing_x_ref(double y, double yp, 
 // temperatures take the formula.  Relative error 1.5e-13 above 230 K, 1.6e-12 above 200 K, 9e-10 at 137 K (where e_s is
 // 1e-7 hPa): below 1e-12 K in any virtual temperature, seven orders under the parity bar.  (Round 1 carried degree 7,
 // 6e-14 everywhere: two more fp64 instructions and two more LDS reads per evaluation for digits nothing consumes -- 2 %
-// of the family kernel, 5 % of the RK4 one, measured in a same-box A/B.  XP_ES_DEG = 6 / 7 still build.)
+// of the family kernel, 5 % of the RK4 one, measured in a same-box A/B.)
 constexpr double ES_T_LO = 137.0;
 // Row stride 257 doubles: (a) more than the 255 x 8 B reach of ds_read2_b64 and not a multiple of 64, so every
 // coefficient is its own ds_read_b64 (2 LDS cycles, banks (a/4) mod 64) instead of half a ds_read2_b64 (8 cycles per
@@ -163,14 +174,17 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     }
     double r = __builtin_amdgcn_fract(u);            // the polynomials are in T - (left edge of the interval): no way back from the index
     const double *c = tb + i;
-    double p = c[ES_DEG * ES_STRIDE];
-    if (ES_DEG >= 7) p = __builtin_fma(p, r, c[6 * ES_STRIDE]);
-    if (ES_DEG >= 6) p = __builtin_fma(p, r, c[5 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[4 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[3 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[2 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[1 * ES_STRIDE]);
-    p = __builtin_fma(p, r, c[0]);
+    // all coefficients requested, then ONE s_waitcnt lgkmcnt(0): left alone the compiler waits for each coefficient just
+    // before its fma (lgkmcnt(4), (3), ... : five more instructions per evaluation, each of which takes an issue slot)
+    static_assert(ES_DEG == 5, "es_tab is written out for degree 5");
+    double k0 = c[0], k1 = c[1 * ES_STRIDE], k2 = c[2 * ES_STRIDE], k3 = c[3 * ES_STRIDE], k4 = c[4 * ES_STRIDE], k5 = c[5 * ES_STRIDE];
+    lds_wait_all();
+    double p = k5;
+    p = __builtin_fma(p, r, k4);
+    p = __builtin_fma(p, r, k3);
+    p = __builtin_fma(p, r, k2);
+    p = __builtin_fma(p, r, k1);
+    p = __builtin_fma(p, r, k0);
     if (!all_in_range) {
         // behind a wave-uniform test and an asm barrier so that the compiler cannot fold the slow path into the
         // fast one as a select
@@ -196,7 +210,9 @@ template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) 
     int e = __builtin_amdgcn_frexp_exp(x);
     double m = __builtin_amdgcn_frexp_mant(x);
     int i = (__double2hiint(x) >> 14) & (LOG_N - 1);       // the top six fraction bits = floor(128 m) - 64 (one v_bfe_u32)
-    double r = __builtin_fma(m, lt[i], -1.0);
+    const double rc = lt[i], lc = lt[ES_STRIDE + i];
+    lds_wait_all();
+    double r = __builtin_fma(m, rc, -1.0);
     double q;
     if (SHORT) {
         q = fma_sc(0.2, r, -0.25);
@@ -208,7 +224,7 @@ template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) 
     q = fma_sc(q, r, 1.0 / 3.0);
     q = __builtin_fma(q, r, -0.5);
     q = __builtin_fma(q, r, 1.0);
-    return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lt[ES_STRIDE + i]));
+    return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lc));
 }
 XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p, bool fast = false) {
     return EPS * fdiv(es_tab(tb, td, fast), p - es_tab(tb, t, fast));
@@ -472,9 +488,13 @@ struct Family {
 #pragma unroll
         for (int n = 0; n <= FAM_ND; ++n) {
             const double *r = a + n * FAM_SN;
-            double v = r[FAM_MD * FAM_SM];
+            double k[FAM_MD + 1];
 #pragma unroll
-            for (int m = FAM_MD - 1; m >= 0; --m) v = __builtin_fma(v, s, r[m * FAM_SM]);
+            for (int m = 0; m <= FAM_MD; ++m) k[m] = r[m * FAM_SM];
+            lds_wait_all();                              // nine reads in flight, one wait
+            double v = k[FAM_MD];
+#pragma unroll
+            for (int m = FAM_MD - 1; m >= 0; --m) v = __builtin_fma(v, s, k[m]);
             asm volatile("" : "+v"(v) : : "memory");     // this row is finished before the next row's reads are issued
             c[n] = v;
         }
@@ -586,9 +606,13 @@ struct Family {
         double b[FAM_MD + 1];
 #pragma unroll
         for (int m = 0; m <= FAM_MD; ++m) {
-            double v = a[m * FAM_SM + FAM_ND * FAM_SN];
+            double k[FAM_ND + 1];
 #pragma unroll
-            for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, a[m * FAM_SM + n * FAM_SN]);
+            for (int n = 0; n <= FAM_ND; ++n) k[n] = a[m * FAM_SM + n * FAM_SN];
+            lds_wait_all();
+            double v = k[FAM_ND];
+#pragma unroll
+            for (int n = FAM_ND - 1; n >= 0; --n) v = __builtin_fma(v, z, k[n]);
             asm volatile("" : "+v"(v) : : "memory");
             b[m] = v;
         }
@@ -788,7 +812,7 @@ struct Scan {
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
         if (!LEAN && pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                  // lowest valid pressure so far = the last one (LEAN: the kernel tracks the level index instead)
-        top_le = valid ? (par <= env) : top_le;
+        top_le = (valid & (par <= env)) | (!valid & top_le);                      // (mask logic on the scalar unit: as a select the compiler round-trips the booleans through VGPRs)
         any_valid = any_valid || valid;
         if (is_lcl) { slot[SL_CAPE_LCL * SLOT_STRIDE] = cape; slot[SL_CIN_LCL * SLOT_STRIDE] = cin; }
         Xp = X; yp = y; parp = par; ++j;

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     auto lcl_environment = [&](double pa, double xa, double ta, double tda, double &te, double &tde) __attribute__((always_inline)) {
         double at = log_interp ? x_lcl : l.p;
         const double pb = br[SL_BR_P * SLOT_STRIDE], xb = br[SL_BR_X * SLOT_STRIDE], tb_ = br[SL_BR_T * SLOT_STRIDE], tdb = br[SL_BR_TD * SLOT_STRIDE];
+        lds_wait_all();
         double cb = log_interp ? xb : pb, ca = log_interp ? xa : pa;
         double ta2 = ta, tda2 = tda;
         if (pb == l.p) { ca = cb; ta2 = tb_; tda2 = tdb; }                 // a level sits exactly on the LCL
@@ -540,9 +541,15 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             }
         }
     } else {
-        for (; k <= nlev; ++k) {
+        // (counted DOWN: `rem` levels are still to be taken out of the look-ahead buffer, so the loop compares against 0 and
+        // 1 and the level count itself is not live in it -- it used to be spilled and read back, eight v_readlane per level)
+        int rem = nlev - k;
+        asm volatile("" : "+s"(rem));
+        for (; rem >= 0; --rem, ++k) {
             const double P = sP, T_ = sT, M_ = sM;
-            next_level(k, sP, sT, sM);
+            const bool in = rem > 0;
+            sP = in ? np_ : qnan(); sT = in ? nt_ : qnan(); sM = in ? ntd_ : qnan();
+            if (rem > 1) load3(np_, nt_, ntd_);
             cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
