@@ -505,19 +505,23 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     const int nlev = (int)a.nlev;                                          // the host checks nlev < 2^31: 32-bit scalar compares in the loops
     seek(k);
     if (k < nlev) load3(np_, nt_, ntd_);
-    // level k out of the look-ahead buffer (NaN past the top), level k + 1 requested
-    auto next_level = [&](int kk, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
-        const bool in = kk < nlev;
-        P_ = in ? np_ : qnan(); T2_ = in ? nt_ : qnan(); M_ = in ? ntd_ : qnan();
-        if (kk + 1 < nlev) load3(np_, nt_, ntd_);
+    // Level out of the look-ahead buffer, the next one requested.  The buffer itself holds NaN once the levels are used up
+    // (no select per level), and the wave-uniform loops count DOWN -- `rem` levels not yet taken out of the buffer -- so
+    // that they compare against 0 and 1 and the level count is not live in them (it used to be spilled and read back with
+    // eight v_readlane per level).
+    auto take = [&](bool more, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
+        P_ = np_; T2_ = nt_; M_ = ntd_;
+        if (more) load3(np_, nt_, ntd_);
+        else { np_ = qnan(); nt_ = qnan(); ntd_ = qnan(); }
     };
     constexpr bool Q = HUM && !PROFILE;
-    for (; k <= nlev; ++k) {                                             // phase A
+    for (; k <= nlev; ++k) {                                             // phase A (the searching parcels: per-lane level index)
         if (__ballot(!lcl_done || (PREP && s_is_td)) == 0ull) break;       // wave-uniform: everybody is above its LCL
         double P, T_, M_;
-        next_level(k, P, T_, M_);
+        take(k + 1 < nlev, P, T_, M_);
         source(std::true_type{}, P, T_, M_, k >= nlev, k);
     }
+    // (counting phase A down as well costs the surface / explicit-parcel kernels 60-70 spilled VGPRs at the 128 cap: measured)
     // Phase B: every lane is past its LCL and one level behind the loads: the level in (sP, sT, sM) is fed while the next
     // one arrives; the iteration past the top level feeds the last one.
     if (SEARCH) {
@@ -530,10 +534,13 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         int ku = nlev + 1;
         for (int probe = 0; probe <= nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
         seek(ku);
+        np_ = qnan(); nt_ = qnan(); ntd_ = qnan();
         if (ku < nlev) load3(np_, nt_, ntd_);
-        for (; ku <= nlev; ++ku) {
+        int rem = nlev - ku;
+        asm volatile("" : "+s"(rem));
+        for (; rem >= 0; --rem, ++ku) {
             double Pn, Tn, Mn;
-            next_level(ku, Pn, Tn, Mn);
+            take(rem > 1, Pn, Tn, Mn);
             if (ku >= resume) {
                 cur_k = ku - 1;
                 moist_node(sP, log_tab<true>(es, sP), sT, Q ? sM : as_dewpoint<HUM>(es, sP, sT, sM), Q);
@@ -541,15 +548,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             }
         }
     } else {
-        // (counted DOWN: `rem` levels are still to be taken out of the look-ahead buffer, so the loop compares against 0 and
-        // 1 and the level count itself is not live in it -- it used to be spilled and read back, eight v_readlane per level)
         int rem = nlev - k;
         asm volatile("" : "+s"(rem));
         for (; rem >= 0; --rem, ++k) {
             const double P = sP, T_ = sT, M_ = sM;
-            const bool in = rem > 0;
-            sP = in ? np_ : qnan(); sT = in ? nt_ : qnan(); sM = in ? ntd_ : qnan();
-            if (rem > 1) load3(np_, nt_, ntd_);
+            take(rem > 1, sP, sT, sM);
             cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
