@@ -14,4 +14,4 @@ bash scripts/run_gpu_fetch.sh ${tag}_c5 c5 family > /dev/null 2>&1 && cp gpurun_
 bash scripts/run_gpu_fetch.sh ${tag}_c2 c2 family > /dev/null 2>&1 && cp gpurun_out/${tag}_c2_fetch.txt gpurun_out/ev/ && echo "done fetch c2"
 python3 scripts/run_gpu_levels.py 2 4 8 16 24 32 48 64 96 128 > gpurun_out/ev/${tag}_levels.json 2>/dev/null && echo "done levels"
 python3 scripts/run_gpu_persist.py > gpurun_out/ev/${tag}_persist.txt 2>/dev/null && echo "done persist"
-python3 bench.py --steps 30 --warmup 5 --no-cpu --no-table-leg --data smooth 2>/dev/null | tail -1 > gpurun_out/ev/${tag}_smooth_bench.json && echo "done smooth"
+python3 bench.py --steps 30 --warmup 5 --no-cpu --no-table-leg --no-config-legs --data smooth 2>/dev/null | tail -1 > gpurun_out/ev/${tag}_smooth_bench.json && echo "done smooth"
