@@ -58,7 +58,7 @@ def algorithmic_bytes_per_column(nlev, itemsize, n_out=2):
 
 def persist_min_cols(parcel):     # csrc/xparcel.hip xp_cape_cin: family mode runs persistent wavefronts on grids this large
     e = os.environ.get('XP_PERSIST_MIN_COLS')
-    return int(e) if e is not None else (1 << 19) if parcel in ('most_unstable', 'mixed_layer') else (4 << 20)
+    return int(e) if e is not None else (1 << 19) if parcel in ('most_unstable', 'mixed_layer') else (3 << 18)
 
 
 def kernel_name(dtype, parcel, moist, humidity, ncol):

@@ -517,12 +517,14 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
         HIP_TRY(hipMallocAsync(&flags, sizeof(int32_t) * (size_t)a.ncol, st.s));   // stream-ordered scratch: which columns need RK4
         st.scratch.push_back(flags);                         // released by the Stager on every path out of this function
         a.flags = (int32_t *)flags;
-        // large grids run persistent wavefronts (k_cape_cin, PERSIST); XP_PERSIST_MIN_COLS: A/B.  Measured
-        // (scripts/run_gpu_persist.py): the searching parcels gain 4-14 % from 1 Mi columns on (uneven work per wavefront),
-        // the surface / explicit parcel 2-3 % from 4 Mi columns.
+        // larger grids run persistent wavefronts (k_cape_cin, PERSIST); XP_PERSIST_MIN_COLS: A/B.  Measured per grid size
+        // (profiles/r03_persist.txt, scripts/run_gpu_persist.py): equal to the ordinary launch up to two rounds of
+        // workgroups (512 Ki columns), 10-13 % faster from three rounds on (768 Ki ... 2 Mi columns of 64 f64 levels; c2:
+        // 0.64 -> 0.575 ms) -- a workgroup's sixteen wavefronts no longer wait for the slowest of them before the next
+        // sixteen tiles start.  (Round 2's kernels gained nothing from it below 4 Mi columns.)
         static const long long persist_env = [] { const char *e = getenv("XP_PERSIST_MIN_COLS"); return e ? atoll(e) : -1ll; }();
         const bool searching = parcel->mode == XP_PARCEL_MOST_UNSTABLE || parcel->mode == XP_PARCEL_MIXED_LAYER;
-        const long long persist_min = persist_env >= 0 ? persist_env : searching ? (1ll << 19) : (4ll << 20);
+        const long long persist_min = persist_env >= 0 ? persist_env : searching ? (1ll << 19) : (3ll << 18);
         a.persist = (long long)a.ncol >= persist_min && a.ncol < (1ll << 36);
     }
     if (p->dtype == XP_F64) launch_cape_pm<double>(a, parcel->mode, profile != nullptr, st.s);
