@@ -25,8 +25,9 @@ Legs measured after the headline (never a reason to lose it: each one is guarded
             fused pass of xp_cape_cin_multi), each with kernel_ms, frac on SURVEY 8(d)'s algorithmic bytes and a strided
             >= 4000-column check against the oracle; "cpu_baseline_numpy" (the one-column NumPy restatement, the closest
             analogue of the reference's xarray / NumPy path, on <= 2048 columns).  --leg-scale N divides their column counts.
-  N > 1 GPUs, --config c2 (the driver's command line):  "strong_c4": the FIXED 128 x 8192 x 8192 f32 grid of config 4 cut
-            into N y-slabs (SURVEY 8e's strong-scaling curve), same step / gather / timing protocol as the headline.
+  any N, --config c2 (the driver's command line):  "strong_c4": the FIXED 128 x 8192 x 8192 f32 grid of config 4 cut into N
+            y-slabs (SURVEY 8e's strong-scaling curve; N = 1: the whole 103 GB grid on the one GPU), same step / gather /
+            timing protocol as the headline.
 """
 import argparse
 import glob
@@ -419,6 +420,21 @@ def main():
         return dict(dt=dt, last=last, kernel_ms=kernel_ms, ncol=ncol, total_rows=total_rows, nlev=nlev, nx=nx, parcels=parcels,
                     timed_steps=timed_steps, tdt=tdt)
 
+    def strong_leg(c4):
+        """SURVEY 8(e)'s fixed-grid point for this N: config 4's ONE grid cut into `world` y-slabs, the headline's protocol."""
+        nst = max(2, min(a.steps, 5))
+        s4 = run_cfg(c4, a.moist, nst, 1)
+        k4 = sum(e0.elapsed_time(e1) for e0, e1 in s4['kernel_ms']['surface']) / len(s4['kernel_ms']['surface'])
+        leg = {'what': f"BASELINE config 4 (strong scaling): ONE fixed {c4['nlev']}-level x {c4['ny']} x {c4['nx']} f32 grid cut into {world} y-slab(s), "
+                       f"surface_based_cape_cin{' + one gather per step' if world > 1 else ''}; same timing protocol as the headline",
+               'scaling': 'strong', 'n_gpus': world, 'steps': nst, 'columns_total': s4['total_rows'] * s4['nx'], 'columns_this_rank': s4['ncol'],
+               'value': s4['total_rows'] * s4['nx'] * nst / s4['dt'], 'unit': 'column-profiles/s', 'ms_per_step': s4['dt'] / nst * 1e3,
+               'kernel_ms_rank0': k4, 'frac_rank0': algorithmic_bytes_per_column(c4['nlev'], 4) * s4['ncol'] / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               'check': {'max_cape': float(s4['last']['surface']['cape'].max())}}
+        s4 = None
+        torch.cuda.empty_cache()
+        return leg
+
     h = run_cfg(cfg, a.moist, a.steps, a.warmup)
     dt, last, kernel_ms, ncol, total_rows = h['dt'], h['last'], h['kernel_ms'], h['ncol'], h['total_rows']
     nlev, nx, parcels = h['nlev'], h['nx'], h['parcels']
@@ -433,16 +449,7 @@ def main():
         per_parcel_head = {pc: sum(e0.elapsed_time(e1) for e0, e1 in v) / len(v) for pc, v in kernel_ms.items()}
         h = last = None                                            # the headline's grid makes room
         torch.cuda.empty_cache()
-        s4 = run_cfg(c4, a.moist, max(2, min(a.steps, 5)), 1)
-        k4 = sum(e0.elapsed_time(e1) for e0, e1 in s4['kernel_ms']['surface']) / len(s4['kernel_ms']['surface'])
-        nst = max(2, min(a.steps, 5))
-        strong = {'what': f"BASELINE config 4 (strong scaling): ONE fixed {c4['nlev']}-level x {c4['ny']} x {c4['nx']} f32 grid cut into {world} y-slabs, "
-                          f"surface_based_cape_cin + one gather per step; same timing protocol as the headline",
-                  'scaling': 'strong', 'n_gpus': world, 'steps': nst, 'columns_total': s4['total_rows'] * s4['nx'], 'columns_this_rank': s4['ncol'],
-                  'value': s4['total_rows'] * s4['nx'] * nst / s4['dt'], 'unit': 'column-profiles/s', 'ms_per_step': s4['dt'] / nst * 1e3,
-                  'kernel_ms_rank0': k4, 'check': {'max_cape': float(s4['last']['surface']['cape'].max())}}
-        s4 = None
-        torch.cuda.empty_cache()
+        strong = strong_leg(c4)
     if rank == 0:
         item = 8 if cfg['dtype'] == 'f64' else 4
         per_parcel = per_parcel_head if strong is not None else {pc: sum(e0.elapsed_time(e1) for e0, e1 in v) / len(v) for pc, v in kernel_ms.items()}
@@ -522,6 +529,13 @@ def main():
                 out.update(config_legs(a, dev, a.moist))
             except Exception as e:
                 out['config_legs_error'] = str(e)
+            try:                                            # the N = 1 point of the fixed-grid curve: the whole 103 GB grid on this GPU
+                c4 = dict(CONFIGS['c4'])
+                c4['ny'] = max(1, c4['ny'] // max(1, a.leg_scale))
+                out['strong_c4'] = strong_leg(c4)
+            except Exception as e:
+                out['strong_c4'] = {'error': str(e)}
+                torch.cuda.empty_cache()
             if not a.no_cpu:
                 try:
                     out['cpu_baseline_numpy'] = cpu_baseline_numpy(cfg['seed'], nlev, 2048 if not a.cpu_sample else max(32, min(2048, a.cpu_sample // 16)))

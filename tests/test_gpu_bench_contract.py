@@ -45,6 +45,8 @@ def test_bench_json_contract():
     assert c5['fused_step']['bitwise_equal_to_two_passes'] is True and c5['fused_step']['kernel_ms'] > 0
     n = d['cpu_baseline_numpy']
     assert n['kind'] == 'port' and n['cores'] == 1 and n['value'] > 0
+    s4 = d['strong_c4']                                    # the N = 1 point of SURVEY 8(e)'s fixed-grid curve
+    assert s4['scaling'] == 'strong' and s4['n_gpus'] == 1 and s4['columns_total'] == (8192 // 256) * 8192 and s4['value'] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_rehearsal():
