@@ -50,9 +50,9 @@ for seed, nlev, parcel, mode, dtype in itertools.product(seeds, (9, 33, 64, 100)
             print('MISMATCH (fused)', seed, nlev, parcel, mode, dtype.__name__, str(e)[:300], flush=True)
     try:
         if mode == 0 and variant != 'specific':      # the CAPE / CIN-only (LEAN) instantiation: bit-identical to the all-outputs kernel
-            lean = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, want=('cape', 'cin', 'lfc_pressure', 'el_pressure', 'status'))
+            lean = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=variant, want=('cape', 'cin', 'lfc_pressure', 'el_pressure'))
             for k in lean:
-                assert np.array_equal(np.asarray(lean[k]), np.asarray(got[k]), equal_nan=k != 'status'), ('lean kernel differs', k)
+                assert np.array_equal(np.asarray(lean[k]), np.asarray(got[k]), equal_nan=True), ('lean kernel differs', k)
         tp._compare(got, ref, dtype, 1e-6)
     except AssertionError as e:
         bad += 1

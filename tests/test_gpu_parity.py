@@ -133,18 +133,21 @@ def test_columns_vs_oracle(parcel, mode, dtype):
 @pytest.mark.parametrize('moist', ['exact', 'family'])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_cape_cin_only_kernels_vs_oracle(parcel, moist, dtype):
-    """The LEAN instantiations (default options, no LFC / EL temperatures or indices requested -- what bench.py and a
-    multi-GPU gather launch): CAPE, CIN, the LFC / EL pressures, status and parcel index against the oracle, every
+    """The LEAN instantiations (default options; no LFC / EL temperatures, indices or status word requested -- what bench.py
+    and a multi-GPU gather launch): CAPE, CIN, the LFC / EL pressures and the parcel index against the oracle, every
     column, NaN / saturated columns included.  Without the indices the saturated-parcel label ties cannot be told apart
     here, so CAPE / CIN of the (few) columns the all-outputs kernel would classify as ties are compared at 1e-6 all the
     same -- a label tie leaves the values alone -- and only a sign tie (bounded in test_columns_vs_oracle) may differ."""
     p, t, td = synth.columns(nlev=64, ncol=12000, seed=31, nan_fraction=0.08, dtype=dtype)
-    want = ('cape', 'cin', 'lfc_pressure', 'el_pressure', 'status', 'parcel_index', 'lcl_pressure', 'parcel_pressure')
+    # (the status word is tracked by the all-outputs kernels only: asking for it takes the call out of the LEAN dispatch)
+    want = ('cape', 'cin', 'lfc_pressure', 'el_pressure', 'parcel_index', 'lcl_pressure', 'parcel_pressure')
     got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want=want)
     full = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist)             # the all-outputs kernel, same call otherwise
     for k in want:
         a, b = np.asarray(got[k]), np.asarray(full[k])
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == 'f'), k              # identical to the generic kernel, bit for bit
+    got['status'] = xa.cape_cin_columns(p, t, td, parcel=parcel, moist=moist, want=('cape', 'cin', 'status'))['status']
+    assert np.array_equal(np.asarray(got['status']), np.asarray(full['status']))
     ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='rk4' if moist == 'exact' else 'family')
     _, excluded = _saturated_tie_columns(full, ref)
     keep = ~excluded

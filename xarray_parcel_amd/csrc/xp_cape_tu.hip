@@ -43,7 +43,7 @@ template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeAr
     // always took the generic kernel) and runs 2.5-5 % faster than the generic one (same-box A/B); DEF
     // alone still spills for the searching parcels (40-55 VGPRs) and stays with the generic kernel.
     // tests/test_kernel_resources.py watches the numbers this rule rests on.
-    const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx;     // no LFC / EL temperatures or indices wanted
+    const bool lean = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx && !a.s.status;   // no LFC / EL temperatures, indices or status word wanted
     const bool dflt = a.vtc && a.pos_neg && a.log_interp;                           // the reference's defaults (pf.py:1396, 1293)
     if (dflt && lean) { hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a); return; }
     if constexpr (MODE != 2) {

@@ -788,7 +788,8 @@ struct Scan {
         }
         add((y * 0.5) * fabs(X - zlog));                                    // upper triangle
     }
-    // LEAN: only CAPE / CIN (and the LFC / EL pressures) are wanted -- the LFC / EL temperatures and interval indices are not
+    // LEAN: only CAPE / CIN (and the LCL / LFC / EL pressures) are wanted -- no LFC / EL temperatures, interval indices or status word:
+    // they are not
     // recorded, and the lowest valid pressure is left to the caller (three LDS writes less per crossing, one per level)
     template <bool LEAN = false, bool ABOVE = false> XP_DEV void node(double P, double X, double par, double env, bool is_lcl) {
         if (is_lcl) {                                                       // the bracket is spent: SL_A* become the LFC record
@@ -807,8 +808,10 @@ struct Scan {
         add(same ? a : 0.0);
         if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN, ABOVE>(X, par, env, y, a);
         pos_parcel = pos_parcel || ((ABOVE || P < p_lcl) && par > env);     // pf.py:1166-1169 (ABOVE: a NaN pressure comes with a NaN parcel)
-        bad_p = bad_p || (X > Xp);                                          // NaN compares false: a missing pressure is not "bad"
-        env_any = env_any || !isnan_(env);
+        if (!LEAN) {                                                        // status bits (LEAN: the caller did not ask for `status`)
+            bad_p = bad_p || (X > Xp);                                      // NaN compares false: a missing pressure is not "bad"
+            env_any = env_any || !isnan_(env);
+        }
         bool pv = !isnan_(P);
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
         if (!LEAN && pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                  // lowest valid pressure so far = the last one (LEAN: the kernel tracks the level index instead)

@@ -316,7 +316,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     int jout = 0;                                                           // profile row
     double li_d = qnan();                                                   // PROFILE: environment minus parcel temperature of the node before this one (lifted index)
     bool li_done = false;
-    int last_k = -1, cur_k = -1;                                            // LEAN: level index of the last valid-pressure node / of the node being fed
+    // CAPE / CIN-only kernels and the lowest valid pressure of the profile (stands in for a missing EL, pf.py:1329): recovered
+    // after the walk (below) -- except for the mixed-layer parcel, whose kernels the register allocator serves better with
+    // the per-node bookkeeping (17-27 spilled VGPRs otherwise): the level index of the last valid-pressure node
+    constexpr bool TRACK = LEAN && PMODE == PM_ML;
+    int last_k = -1, cur_k = -1;
     // `above` (a std::integral_constant): this node and the one before it lie strictly above the LCL (phase B)
     auto emit = [&](auto above, double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
                 if (!isnan_(P)) { if (LI_SLOT) sc.slot[(LI_SLOT ? SL_LI : 0) * SLOT_STRIDE] = d_; else li_d = d_; }
             }
         }
-        if (LEAN) {      // the lowest valid pressure = the last valid node: remember which level it was instead of storing P
+        if (TRACK) {
             if (!isnan_(P)) { last_k = (is_lcl || cur_k < 0) ? -1 : cur_k; if (is_lcl || cur_k < 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = P; }
         }
         sc.template node<LEAN, decltype(above)::value>(P, X, vtc ? tvp : tp, vtc ? tve : te, is_lcl);
@@ -428,11 +432,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         const double M_ = skew ? sM : Mc;
         double Td_ = (decltype(raw)::value && !(PREP && skew && s_is_td)) ? as_dewpoint<HUM>(es, P, T_, M_) : M_;
         if (fabs(P - l.p) <= LCL_SNAP * l.p) P = l.p;                       // on the LCL (see xp::lcl)
-        cur_k = skew ? kc - 1 : kc;
         double X = log_tab<true>(es, P);
         X = (P == l.p) ? x_lcl : X;
+        if (TRACK) cur_k = skew ? kc - 1 : kc;
         const bool cross = !skew && (last || P < l.p);
-        if (isnan_(P) && !skew && !last) status |= 4;                      // NaN pressure below the LCL (see xparcel.h)
+        if (!LEAN && isnan_(P) && !skew && !last) status |= 4;             // NaN pressure below the LCL (see xparcel.h)
         // only the parcel temperature / mixing ratio is branched, the environment and the scan node are shared
         double tp, tvp;
         if (!skew) {                                                       // dry adiabat (pf.py:313, 767)
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             double Pn, Tn, Mn;
             take(rem > 1, Pn, Tn, Mn);
             if (ku >= resume) {
-                cur_k = ku - 1;
+                if (TRACK) cur_k = ku - 1;
                 moist_node(sP, log_tab<true>(es, sP), sT, Q ? sM : as_dewpoint<HUM>(es, sP, sT, sM), Q);
                 sP = Pn; sT = Tn; sM = Mn;
             }
@@ -553,11 +557,26 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         for (; rem >= 0; --rem, ++k) {
             const double P = sP, T_ = sT, M_ = sM;
             take(rem > 1, sP, sT, sM);
-            cur_k = k - 1;
+            if (TRACK) cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
     }
-    if (LEAN && last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
+    if (TRACK) {
+        if (last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
+    } else if (LEAN) {
+        // The lowest valid pressure of the profile (what stands in for a missing EL, pf.py:1329) is not tracked per node in
+        // the CAPE / CIN-only kernels: pressures decrease along the profile, so it is the smaller of the LCL pressure and the
+        // last level with a valid pressure -- found now by looking down from the top (one load per lane unless the top is
+        // missing).  (The mixed-layer parcel's own node lies at or below its LCL, so it never is the minimum.)
+        double pm = l.p;
+        bool found = false;
+        for (int kk = nlev - 1; kk >= (int)pc.first; --kk) {
+            if (__ballot(!found) == 0ull) break;
+            const double q = ld<T>(a.p, kk, c);
+            if (!found && !isnan_(q)) { pm = (q < pm) ? q : pm; found = true; }
+        }
+        sc.slot[SL_MIN_P * SLOT_STRIDE] = pm;
+    }
     if (PROFILE) {
         for (; jout < a.prof.nlev_out; ++jout) {
             int64_t o = jout * a.prof.ls + c * a.prof.cs;
