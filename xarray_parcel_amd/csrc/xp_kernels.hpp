@@ -490,7 +490,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // software-prefetched level loop
     // Three per-lane row pointers that WALK up the levels: set once (64-bit multiply-add, a quarter-rate instruction),
     // then advanced by the row stride with two full-rate adds per array and level.
-    const int64_t lane_off = (int64_t)c * a.p.cs * (int64_t)sizeof(T), row_step = a.p.ls * (int64_t)sizeof(T);
+    const int64_t lane_off = (int64_t)c * a.p.cs * (int64_t)sizeof(T);
+    const int64_t row_step = a.p.ls * (int64_t)sizeof(T);
     // (address space 1 = global, spelled out: behind the asm barrier below the compiler would otherwise fall back to
     // flat loads, which also count against the LDS counter and so make every LDS wait a memory wait)
     typedef const char __attribute__((address_space(1))) *GPtr;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // (counting phase A down as well costs the surface / explicit-parcel kernels 60-70 spilled VGPRs at the 128 cap: measured)
     // Phase B: every lane is past its LCL and one level behind the loads: the level in (sP, sT, sM) is fed while the next
     // one arrives; the iteration past the top level feeds the last one.
-    if (SEARCH) {
+    if constexpr (SEARCH) {
         // ... with a WAVE-UNIFORM level index.  The columns of a searching parcel start at their own levels, so after
         // phase A the lanes stand on different levels and every load would touch as many level rows as there are distinct
         // positions (the most-unstable kernel fetched 3.7 x its algorithmic bytes: 6.4 L2 requests per load instead of 2).
