@@ -745,6 +745,33 @@ struct Scan {
         // crossing within 2e-9 (in ln p) of the LCL, whose "p* < p_lcl" tie is broken with the library exp / log
         // exactly as on the CPU.
         double d = y - yp, xs, frac;
+        if constexpr (ABOVE) {
+            // Strictly above the LCL (the kernel's phase B, most of a column): no duplicated pressure can occur there (the
+            // only one a profile has is the LCL node on a level), and ONE test covers every "no valid zero" case -- y, yp, X
+            // or Xp missing makes xs NaN, and then both triangles and the plain trapezoid are NaN too: nothing to add,
+            // nothing to record.  (Twelve instructions less than the general form below on a path that some lane of a
+            // wavefront takes at ~90 % of the levels of the bench's columns.)
+            const double r = frcp(d);
+            xs = (y * Xp - yp * X) * r;
+            if (isnan_(xs)) return;
+            frac = -yp * r;
+            add((yp * 0.5) * fabs(Xp - xs));                                // lower triangle (pf.py:1246-1273)
+            if (y > 0.0) {                                                  // increasing crossing
+                any_inc = true;
+                if (!(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {                // bottom LFC (pf.py:1127-1132)
+                    slot[SL_LFC_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[0] = j - 1;
+                    if (!LEAN) slot[SL_LFC_T * SLOT_STRIDE] = frac * (par - parp) + parp;     // pf.py:1050
+                    slot[SL_CAPE_LFC * SLOT_STRIDE] = cape; slot[SL_CIN_LFC * SLOT_STRIDE] = cin;
+                }
+            }
+            if (y < 0.0 && !(xs >= slot[SL_EL_X * SLOT_STRIDE])) {          // top EL (pf.py:1136-1138)
+                slot[SL_EL_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[1] = j - 1;
+                if (!LEAN) slot[SL_EL_T * SLOT_STRIDE] = frac * (par - parp) + parp;
+                slot[SL_CAPE_EL * SLOT_STRIDE] = cape;
+            }
+            add((y * 0.5) * fabs(X - xs));                                  // upper triangle
+            return;
+        }
         bool dup = (X == Xp);
         if (__builtin_amdgcn_ballot_w64(dup) != 0ull && dup) {
             xs = (y * Xp - yp * X) / d;                                     // pf.py:1046
@@ -816,7 +843,7 @@ struct Scan {
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
         if (!LEAN && pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                  // lowest valid pressure so far = the last one (LEAN: the kernel tracks the level index instead)
         top_le = (valid & (par <= env)) | (!valid & top_le);                      // (mask logic on the scalar unit: as a select the compiler round-trips the booleans through VGPRs)
-        any_valid = any_valid || valid;
+        if (!LEAN) any_valid = any_valid || valid;                          // (feeds the status word only)
         if (is_lcl) { slot[SL_CAPE_LCL * SLOT_STRIDE] = cape; slot[SL_CIN_LCL * SLOT_STRIDE] = cin; }
         Xp = X; yp = y; parp = par; ++j;
     }
