@@ -134,7 +134,10 @@ typedef struct {
    `dtype`, all buffers live in `mem`, ncol elements each.
    lfc_index / el_index: index i of the interval (levels i, i+1 of the LCL-augmented profile)
    that holds the chosen crossing; -1 = none; lfc_index -2 = LFC replaced by the LCL (pf.py:1161-1185).
-   parcel_index: source level of the lifted parcel (0 for surface, MU level for most-unstable, -1 otherwise). */
+   parcel_index: source level of the lifted parcel (0 for surface, MU level for most-unstable, -1 otherwise).
+   Cost: with default options and lfc_temperature, el_temperature, lfc_index, el_index and status all NULL the
+   pass runs the CAPE/CIN-only kernels (3-5 % faster); any of the five selects the all-outputs kernels.  Values
+   of the arrays that are written do not depend on which kernel ran. */
 typedef struct {
     void *cape, *cin;                                   /* J/kg (pf.py:1361-1385) */
     void *lcl_pressure, *lcl_temperature, *lcl_virtual_temperature; /* pf.py:609-682 */
@@ -305,6 +308,64 @@ typedef struct {
     int32_t *positive_shear;
 } xp_conv_out;
 int xp_conv_properties(const xp_conv_in *in, const xp_opts *opts, int32_t ignore_nans, xp_conv_out *out, void *stream);
+
+/* ---- Array primitives of the reference's implementation -------------------------------------------------------------
+   The CAPE / CIN kernels stream a column once and never build the arrays these functions return, but the reference
+   exposes them (and its tests call two of them), so a caller of the reference finds them here too.  One variable per
+   call; every view of a call shares shape, dtype and mem; outputs are DENSE C-order (rows, ncol) arrays of that dtype
+   in that mem, allocated by the caller.  Arithmetic follows the reference's expressions operation by operation. */
+
+/* pf.py:933-990 insert_level, one variable: out (nlev + 1, ncol) = `variable` with level_value inserted after every
+   level whose coordinate is >= level_coord (an equal coordinate stays BELOW the new level, pf.py:950-954).  For the
+   coordinate itself pass variable = coords, level_value = level_coord.  Rows whose coordinate is NaN come out NaN in
+   every variable, and so does a value equal to fill_value (the reference's -999 trick, pf.py:962-966, 988; its assert
+   that the data holds no fill_value is not evaluated). */
+int xp_insert_level(const xp_view *coords, const xp_view *variable, const void *level_coord, const void *level_value,
+                    double fill_value, void *out, void *stream);
+
+/* pf.py:992-1064 find_intersections of a(x) and b(x) (b NULL = zero): six (nlev - 1, ncol) arrays, each nullable --
+   all_intersect_x, all_intersect_y, increasing_x, increasing_y, decreasing_x, decreasing_y; row i describes the interval
+   between levels i and i + 1 (the reference's label i + 1 on 'offset_dim'); log_x: interpolate in ln x (pf.py:1014, 1053). */
+int xp_find_intersections(const xp_view *x, const xp_view *a, const xp_view *b, int32_t log_x, void *const out[6], void *stream);
+
+/* pf.py:164-206 trapz of one variable: out[c] = sum over intervals of |dx| * mean(dat), NaN areas skipped; mask
+   (nullable): (nlev - 1, ncol) bytes in the views' mem, interval i counts when non-zero. */
+int xp_trapz(const xp_view *dat, const xp_view *x, const uint8_t *mask, int32_t only_positive, int32_t only_negative,
+             void *out, void *stream);
+
+/* pf.py:1200-1289 trap_around_zeros (start = 0): areas = area, dx, x, x_from, x_to, each (2 nlev - 1, ncol), nullable:
+   rows 0 .. nlev-1 the areas just BEFORE a zero of y (level k and the zero in (k, k+1)), rows nlev .. 2 nlev-2 the areas
+   just AFTER (the zero of interval i and level i + 1) -- the reference's concat of the two families (pf.py:1273).
+   mask (nullable): (nlev, ncol) bytes, 1 where the "before" area is NaN (pf.py:1282-1287). */
+int xp_trap_around_zeros(const xp_view *x, const xp_view *y, int32_t log_x, void *const areas[5], uint8_t *mask, void *stream);
+
+/* pf.py:208-227 bound_pressure: the pressure of the column closest to bound[c] (the larger of two equally close). */
+int xp_bound_pressure(const xp_view *pressure, const void *bound, void *out, void *stream);
+
+/* pf.py:63-100 get_layer, one variable: the lowest `depth` hPa of the column (from its highest pressure), NaN outside.
+   interpolate != 0: the layer top is inserted as a level (variable interpolated in ln p; the pressure variable --
+   variable_is_pressure -- takes the top pressure itself): out (nlev + 1, ncol).  interpolate == 0: the top is the
+   nearest existing level (bound_pressure): out (nlev, ncol). */
+int xp_get_layer(const xp_view *pressure, const xp_view *variable, double depth, int32_t interpolate,
+                 int32_t variable_is_pressure, void *out, void *stream);
+
+/* pf.py:1699-1720 shift_out_nans, one variable: every column moved down by the number of leading NaNs of `name`. */
+int xp_shift_out_nans(const xp_view *name, const xp_view *variable, void *out, void *stream);
+
+/* pf.py:1517-1555 from_most_unstable_parcel (XP_PARCEL_MOST_UNSTABLE) / pf.py:1604-1649 mix_layer
+   (XP_PARCEL_MIXED_LAYER): the profile re-based on its parcel.  Levels below the most-unstable parcel / inside the
+   mixed layer are masked, levels left without a value in every column of the grid are dropped (dropna(how='all')),
+   every column is shifted onto its first remaining level and, for the mixed layer, the parcel is put underneath.
+   out_*: (nlev [+ 1 for the mixed layer], ncol), rows >= *nlev_out NaN; parcel: parcel_pressure / temperature /
+   dewpoint / parcel_index of xp_scalars_out (nullable, dtype / mem of the views); level_kept (nullable, HOST, nlev
+   int32): 1 for every input level that survived the drop.  *nlev_out (HOST) = rows in use.  Synchronises the stream. */
+int xp_rebase_profile(const xp_view *pressure, const xp_view *temperature, const xp_view *dewpoint, const xp_parcel *parcel,
+                      void *out_pressure, void *out_temperature, void *out_dewpoint, xp_scalars_out *parcel_out,
+                      int32_t *level_kept, int64_t *nlev_out, void *stream);
+
+/* pf.py:23-37 interp1d_numba = numpy.interp along the levels: at (m, ncol); xp, fp (n, ncol) with xp increasing along
+   the levels (col_stride 0 shares one set of points between the columns); out (m, ncol). */
+int xp_interp1d(const xp_view *at, const xp_view *xp, const xp_view *fp, void *out, void *stream);
 
 const char *xp_last_error(void);
 

@@ -176,16 +176,21 @@ def _r_profile_below(impl, i):
 
 
 def _r_profile_lcl(impl, i):
+    keys = ('pressure', 'environment_temperature', 'temperature')
+    # the fused routine (dewpoint only feeds outputs this KAT does not read) ...
+    fused = impl.parcel_profile_with_lcl(i['p'], i['t'], i['t'], i['parcel_pressure'],
+                                         i['parcel_temperature'], i['parcel_dewpoint'], lcl_interp='linear')
+    prof = fused
     if hasattr(impl, 'add_lcl_to_profile'):
+        # ... and the reference's own call sequence (unit_tests.py:219-226): parcel_profile, then add_lcl_to_profile
         prof = impl.parcel_profile(i['p'], i['parcel_pressure'], i['parcel_temperature'],
                                    i['parcel_dewpoint'])
         prof = impl.add_lcl_to_profile(prof, environment={'temperature': i['t'], 'pressure': prof['pressure']},
                                        interpolator='linear')
-    else:   # same numbers through the fused routine (dewpoint only feeds outputs this KAT does not read)
-        prof = impl.parcel_profile_with_lcl(i['p'], i['t'], i['t'], i['parcel_pressure'],
-                                            i['parcel_temperature'], i['parcel_dewpoint'], lcl_interp='linear')
-    return {'prof.pressure': prof['pressure'], 'prof.environment_temperature': prof['environment_temperature'],
-            'prof.temperature': prof['temperature']}
+        for k in keys:
+            assert np.allclose(np.asarray(prof[k], dtype=np.float64), np.asarray(fused[k], dtype=np.float64), rtol=0, atol=1e-4,
+                               equal_nan=True), k
+    return {'prof.' + k: prof[k] for k in keys}
 
 
 def _r_lcl(impl, i):

@@ -32,9 +32,10 @@ def _api():
     yield
 
 
-@pytest.mark.parametrize('name', sorted(k for k in kr.RECIPES if k != 'test_insert_level'))
+@pytest.mark.parametrize('name', sorted(kr.RECIPES))
 def test_kat_through_c_abi(name):
-    """Every KAT of the reference except test_insert_level (a helper the streaming kernel has no counterpart of)."""
+    """Every KAT of the reference (test_insert_level and test_parcel_profile_lcl through the array primitives of
+    csrc/xp_primitives.hpp, the rest through the streaming kernels)."""
     kr.run(name, xa, loosen=RK4_LOOSEN.get(name))
 
 

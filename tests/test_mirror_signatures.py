@@ -17,9 +17,11 @@ GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '
 EXTRA = {'moist_lapse': {'moist'}, 'surface_cape_vector': {'fused'}, 'melting_level_height': {'moist'}, 'benchmark_cape': {'vert_dim'},
          'dewpoint_from_specific_humidity': set(), 'conv_properties': {'moist'}, 'min_conv_properties': {'moist'},
          'parcel_profile': {'moist'}, 'parcel_profile_with_lcl': {'moist'}, 'wet_bulb_temperature': {'moist'}}
-# deliberately not mirrored: internals of the reference's array implementation that the streaming kernel replaces, its
-# table generator / notebook helpers, and the MetPy / serial comparison legs of the harness
-NOT_MIRRORED_OK = True
+# arguments the reference declares without a default but its callers never pass: `out` of the numba gufunc interp1d_numba
+# (pf.py:23-37: numba allocates it), optional here
+GUFUNC_OUT = {'interp1d_numba': {'out'}}
+# every function of modules/parcel_functions.py is mirrored (test_every_reference_function_is_mirrored); of
+# parcel_test.py only the timing harness is (its MetPy / serial comparison legs need MetPy)
 
 
 def _mirrored(mod, ref):
@@ -40,9 +42,16 @@ def test_signatures_match_the_reference(modname, mod):
         assert set(got[len(want):]) <= EXTRA.get(n, set()), (n, got[len(want):])
         for p, d in zip(params, ref[n]['defaults']):
             if d is None:
-                assert p.default is inspect.Parameter.empty, (n, p.name)
+                assert p.default is inspect.Parameter.empty or p.name in GUFUNC_OUT.get(n, ()), (n, p.name)
             else:
-                assert p.default is not inspect.Parameter.empty and p.default == ast.literal_eval(d), (n, p.name, p.default, d)
+                assert p.default is not inspect.Parameter.empty, (n, p.name)
+                try:
+                    assert p.default == ast.literal_eval(d), (n, p.name, p.default, d)
+                except ValueError:
+                    # an expression (the table grids of moist_adiabat_lookup, pf.py:447-450): same expression text, nothing evaluated
+                    fn = ast.parse(inspect.getsource(getattr(mod, n))).body[0]
+                    dflt = dict(zip([a.arg for a in fn.args.args][len(fn.args.args) - len(fn.args.defaults):], fn.args.defaults))
+                    assert ast.unparse(dflt[p.name]) == ast.unparse(ast.parse(d, mode='eval').body), (n, p.name, d)
         if ref[n]['kwargs']:
             assert any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values()), (n, 'missing **kwargs')
 
@@ -52,7 +61,16 @@ def test_hot_path_functions_are_all_there():
             'parcel_profile_with_lcl', 'lfc_el', 'cape_cin_base', 'lcl', 'moist_lapse', 'dry_lapse', 'most_unstable_parcel',
             'mixed_parcel', 'mixed_layer', 'load_moist_adiabat_lookups', 'wet_bulb_temperature', 'lifted_index',
             'deep_convective_index', 'lapse_rate', 'isobar_temperature', 'freezing_level_height', 'melting_level_height',
-            'wind_shear', 'significant_hail_parameter', 'conv_properties', 'min_conv_properties', 'storm_proxies']
+            'wind_shear', 'significant_hail_parameter', 'conv_properties', 'min_conv_properties', 'storm_proxies',
+            # the array primitives (csrc/xp_primitives.hpp) and the table generators
+            'get_layer', 'trapz', 'bound_pressure', 'insert_level', 'find_intersections', 'trap_around_zeros',
+            'from_most_unstable_parcel', 'mix_layer', 'shift_out_nans', 'add_lcl_to_profile', 'interp1d_numba', 'round_to',
+            'moist_adiabat_lookup', 'moist_adiabat_tables', 'linear_interp', 'log_interp']
     missing = [n for n in need if not hasattr(pf, n)]
     assert not missing, missing
     assert all(n in GOLD['parcel_functions'] for n in need)
+
+
+def test_every_reference_function_is_mirrored():
+    missing = sorted(n for n in GOLD['parcel_functions'] if not (hasattr(pf, n) and callable(getattr(pf, n))))
+    assert missing == [], missing

@@ -23,7 +23,9 @@ ST_TOP_NAN, ST_LCL_NOT_CONVERGED, ST_NAN_PRESSURE, ST_BAD_PRESSURE = 1, 2, 4, 8
 SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_family_table', 'xp_set_family_table', 'xp_cape_cin', 'xp_cape_cin_multi', 'xp_lcl', 'xp_dry_lapse',
            'xp_moist_lapse', 'xp_parcel_profile', 'xp_lfc_el', 'xp_cape_cin_base', 'xp_select_parcel',
            'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_interp_levels', 'xp_dewpoint_from_specific_humidity',
-           'xp_crossing_level', 'xp_mixing_ratio', 'xp_conv_properties', 'xp_last_error')
+           'xp_crossing_level', 'xp_mixing_ratio', 'xp_conv_properties', 'xp_insert_level', 'xp_find_intersections', 'xp_trapz',
+           'xp_trap_around_zeros', 'xp_bound_pressure', 'xp_get_layer', 'xp_shift_out_nans', 'xp_rebase_profile', 'xp_interp1d',
+           'xp_last_error')
 
 
 class View(C.Structure):

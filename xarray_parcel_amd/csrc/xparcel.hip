@@ -1024,3 +1024,6 @@ int xp_mixing_ratio(const xp_view *t, const xp_view *td, const xp_view *p, void 
 }
 
 }  // extern "C"
+
+// the reference's array primitives (insert_level, find_intersections, trapz, ...): kernels + entry points
+#include "xp_primitives_abi.hpp"

@@ -111,7 +111,7 @@ def _view(h, nlev, ncol):
 
 def _alloc(shape, np_dtype, dev, like=None):
     if dev:
-        td = {np.float64: torch.float64, np.float32: torch.float32, np.int32: torch.int32}[np_dtype]
+        td = {np.float64: torch.float64, np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8}[np_dtype]
         t = torch.empty(shape, dtype=td, device=like.t.device if like is not None else 'cuda')
         return t, t.data_ptr()
     a = np.empty(shape, dtype=np_dtype)
@@ -538,6 +538,234 @@ def crossing_level(x, a, value):
     L.check(lib.xp_crossing_level(C.byref(_view(xh, nlev, ncol)), C.byref(_view(ah, nlev, ncol)), C.c_double(float(value)),
                                   C.c_void_p(optr), _stream(dev)))
     return out.reshape(hshape)
+
+
+
+# -- the reference's array primitives (pf.py:63-100, 164-227, 858-1064, 1200-1289, 1517-1555, 1604-1649, 1699-1720) --------
+# The CAPE / CIN kernels never build these arrays; the functions exist because the reference offers them to its callers.
+# Arrays are (nlev, ...) with the vertical first, datasets are dicts name -> array.
+def insert_level(d, level, coords='pressure', fill_value=-999):
+    """pf.py:933: insert `level` (dict name -> one value per column) into the dataset `d` sorted by decreasing `coords`;
+    the keys of `level` define the output (pf.py:983)."""
+    out = {}
+    for k in level.keys():
+        (cds, v), dt, dev = _common(d[coords], d[k])
+        assert cds.shape == v.shape, 'variables of a dataset must share a shape'
+        nlev, ncol, hshape = _vert_shape(cds)
+        lib = L.init(_device_of(cds))
+        lc, lv = _per_col(level[coords], ncol, dt, dev, cds), _per_col(level[k], ncol, dt, dev, cds)
+        arr, ptr = _alloc((nlev + 1, ncol), dt, dev, cds)
+        L.check(lib.xp_insert_level(C.byref(_view(cds, nlev, ncol)), C.byref(_view(v, nlev, ncol)), C.c_void_p(lc.ptr),
+                                    C.c_void_p(lv.ptr), C.c_double(float(fill_value)), C.c_void_p(ptr), _stream(dev)))
+        out[k] = arr.reshape((nlev + 1,) + hshape)
+    return out
+
+
+INTERSECTION_KEYS = ('all_intersect_x', 'all_intersect_y', 'increasing_x', 'increasing_y', 'decreasing_x', 'decreasing_y')
+
+
+def find_intersections(x, a, b=None, log_x=False):
+    """pf.py:992: dict of six (nlev - 1, ...) arrays; entry i belongs to the interval between levels i and i + 1."""
+    ins = (x, a) if b is None else (x, a, b)
+    hs, dt, dev = _common(*ins)
+    xh = hs[0]
+    assert all(h.shape == xh.shape for h in hs), 'x, a, b must share a shape'
+    nlev, ncol, hshape = _vert_shape(xh)
+    lib = L.init(_device_of(xh))
+    outs = [_alloc((nlev - 1, ncol), dt, dev, xh) for _ in INTERSECTION_KEYS]
+    optrs = (C.c_void_p * 6)(*[o[1] for o in outs])
+    bview = C.byref(_view(hs[2], nlev, ncol)) if b is not None else None
+    L.check(lib.xp_find_intersections(C.byref(_view(xh, nlev, ncol)), C.byref(_view(hs[1], nlev, ncol)), bview,
+                                      C.c_int32(int(bool(log_x))), optrs, _stream(dev)))
+    return {k: o[0].reshape((nlev - 1,) + hshape) for k, o in zip(INTERSECTION_KEYS, outs)}
+
+
+def _mask_handle(mask, shape, dev, like):
+    """bool / integer mask -> dense uint8 of `shape` in the memory space of the call."""
+    if _is_torch(mask):
+        if dev:
+            m = (mask != 0).to(torch.uint8).reshape(shape).contiguous().to(like.t.device)
+            return m, m.data_ptr()
+        mask = mask.cpu().numpy()
+    m = np.ascontiguousarray((np.asarray(mask) != 0).reshape(shape), dtype=np.uint8)
+    if dev:
+        m = torch.as_tensor(m).to(like.t.device)
+        return m, m.data_ptr()
+    return m, m.ctypes.data
+
+
+def trapz(dat, x, mask=None, only_positive=False, only_negative=False):
+    """pf.py:164 for one variable (array) or several (dict name -> array): sum of |dx| * mean over the intervals."""
+    assert not (only_positive and only_negative), 'Only negative OR positive regions can be included in trapz.'   # pf.py:200
+    if isinstance(dat, dict):
+        return {k: trapz(v, x, mask=mask, only_positive=only_positive, only_negative=only_negative) for k, v in dat.items()}
+    (d, xh), dt, dev = _common(dat, x)
+    assert d.shape == xh.shape, 'dat and x must share a shape'
+    nlev, ncol, hshape = _vert_shape(d)
+    lib = L.init(_device_of(d))
+    keep, mptr = (None, None) if mask is None else _mask_handle(mask, (max(nlev - 1, 0), ncol), dev, d)
+    out, optr = _alloc((ncol,), dt, dev, d)
+    L.check(lib.xp_trapz(C.byref(_view(d, nlev, ncol)), C.byref(_view(xh, nlev, ncol)), C.c_void_p(mptr),
+                         C.c_int32(int(bool(only_positive))), C.c_int32(int(bool(only_negative))), C.c_void_p(optr), _stream(dev)))
+    del keep
+    return out.reshape(hshape)
+
+
+AREA_KEYS = ('area', 'dx', 'x', 'x_from', 'x_to')
+
+
+def trap_around_zeros(x, y, log_x=True, start=0):
+    """pf.py:1200 (start = 0, the only value the reference uses): (areas, mask).  areas: dict of five (2 nlev - 1, ...)
+    arrays, the areas before the zeros of y (rows 0 .. nlev-1) followed by the areas after them; mask: (nlev, ...) bool,
+    True where no area was taken out of an interval."""
+    assert start == 0, 'only start=0 is implemented (the reference never passes anything else)'
+    (xh, yh), dt, dev = _common(x, y)
+    assert xh.shape == yh.shape, 'x and y must share a shape'
+    nlev, ncol, hshape = _vert_shape(xh)
+    lib = L.init(_device_of(xh))
+    outs = [_alloc((2 * nlev - 1, ncol), dt, dev, xh) for _ in AREA_KEYS]
+    optrs = (C.c_void_p * 5)(*[o[1] for o in outs])
+    mask, mptr = _alloc((nlev, ncol), np.uint8, dev, xh)
+    L.check(lib.xp_trap_around_zeros(C.byref(_view(xh, nlev, ncol)), C.byref(_view(yh, nlev, ncol)), C.c_int32(int(bool(log_x))),
+                                     optrs, C.c_void_p(mptr), _stream(dev)))
+    areas = {k: o[0].reshape((2 * nlev - 1,) + hshape) for k, o in zip(AREA_KEYS, outs)}
+    return areas, (mask != 0).reshape((nlev,) + hshape)
+
+
+def bound_pressure(pressure, bound):
+    """pf.py:208: the pressure of each column closest to `bound` (scalar or one per column)."""
+    (p,), dt, dev = _common(pressure)
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    b = _per_col(bound, ncol, dt, dev, p)
+    out, optr = _alloc((ncol,), dt, dev, p)
+    L.check(lib.xp_bound_pressure(C.byref(_view(p, nlev, ncol)), C.c_void_p(b.ptr), C.c_void_p(optr), _stream(dev)))
+    return out.reshape(hshape)
+
+
+def get_layer(dat, depth=100, interpolate=True):
+    """pf.py:63: dat = dict with 'pressure' and variables; the lowest `depth` hPa, NaN outside; with interpolate the layer top
+    is inserted as a level (nlev + 1 rows)."""
+    out = {}
+    for k, v in dat.items():
+        (p, x), dt, dev = _common(dat['pressure'], v)
+        assert p.shape == x.shape, 'variables of a dataset must share a shape'
+        nlev, ncol, hshape = _vert_shape(p)
+        lib = L.init(_device_of(p))
+        rows = nlev + (1 if interpolate else 0)
+        arr, ptr = _alloc((rows, ncol), dt, dev, p)
+        L.check(lib.xp_get_layer(C.byref(_view(p, nlev, ncol)), C.byref(_view(x, nlev, ncol)), C.c_double(float(depth)),
+                                 C.c_int32(int(bool(interpolate))), C.c_int32(int(k == 'pressure')), C.c_void_p(ptr), _stream(dev)))
+        out[k] = arr.reshape((rows,) + hshape)
+    return out
+
+
+def shift_out_nans(x, name):
+    """pf.py:1699: x = dict name -> array; every column of every variable is moved down by the number of leading NaNs of
+    x[name] in that column."""
+    out = {}
+    for k, v in x.items():
+        (nh, vh), dt, dev = _common(x[name], v)
+        assert nh.shape == vh.shape, 'variables of a dataset must share a shape'
+        nlev, ncol, hshape = _vert_shape(nh)
+        lib = L.init(_device_of(nh))
+        arr, ptr = _alloc((nlev, ncol), dt, dev, nh)
+        L.check(lib.xp_shift_out_nans(C.byref(_view(nh, nlev, ncol)), C.byref(_view(vh, nlev, ncol)), C.c_void_p(ptr), _stream(dev)))
+        out[k] = arr.reshape((nlev,) + hshape)
+    return out
+
+
+def _rebase(pressure, temperature, dewpoint, mode, depth):
+    (p, t, td), dt, dev = _common(pressure, temperature, dewpoint)
+    assert p.shape == t.shape == td.shape, 'pressure, temperature, dewpoint must share a shape'
+    nlev, ncol, hshape = _vert_shape(p)
+    lib = L.init(_device_of(p))
+    pc = L.Parcel(L.PARCEL[mode], 0, float(depth), None, None, None)
+    so = L.ScalarsOut()
+    so.dtype, so.mem = p.xp_dtype, p.mem
+    par = {}
+    for k in L.SCALAR_P + ('parcel_index',):
+        arr, ptr = _alloc((ncol,), np.int32 if k == 'parcel_index' else dt, dev, p)
+        setattr(so, k, ptr)
+        par[k] = arr
+    rows = nlev + (1 if mode == 'mixed_layer' else 0)
+    outs = [_alloc((rows, ncol), dt, dev, p) for _ in range(3)]
+    kept = np.zeros(nlev, dtype=np.int32)
+    nout = C.c_int64(0)
+    L.check(lib.xp_rebase_profile(C.byref(_view(p, nlev, ncol)), C.byref(_view(t, nlev, ncol)), C.byref(_view(td, nlev, ncol)),
+                                  C.byref(pc), C.c_void_p(outs[0][1]), C.c_void_p(outs[1][1]), C.c_void_p(outs[2][1]), C.byref(so),
+                                  kept.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nout), _stream(dev)))
+    n = int(nout.value)
+    arrs = [o[0].reshape((rows,) + hshape)[:n] for o in outs]
+    parcel = {'pressure': par['parcel_pressure'].reshape(hshape), 'temperature': par['parcel_temperature'].reshape(hshape),
+              'dewpoint': par['parcel_dewpoint'].reshape(hshape), 'index': par['parcel_index'].reshape(hshape)}
+    return arrs[0], arrs[1], arrs[2], parcel, kept.astype(bool)
+
+
+def from_most_unstable_parcel(pressure, temperature, dewpoint, depth=300):
+    """pf.py:1517: (pressure, temperature, dewpoint) at and above each column's most-unstable parcel -- levels that no column
+    keeps dropped, columns shifted onto their first kept level -- the parcel, and the mask of input levels that survived."""
+    return _rebase(pressure, temperature, dewpoint, 'most_unstable', depth)
+
+
+def mix_layer(pressure, temperature, dewpoint, depth=100):
+    """pf.py:1604: the profiles with the lowest `depth` hPa replaced by the mixed parcel (row 0), the parcel, and the mask of
+    input levels that survived."""
+    p, t, td, parcel, kept = _rebase(pressure, temperature, dewpoint, 'mixed_layer', depth)
+    parcel.pop('index')
+    return p, t, td, parcel, kept
+
+
+def interp1d(at, xp, fp):
+    """pf.py:23 interp1d_numba = numpy.interp along the vertical: at (m, ...), xp / fp (n, ...) or (n,) shared by all
+    columns; xp increasing along the vertical."""
+    (ah,), dt, dev = _common(at)
+    m, ncol, hshape = _vert_shape(ah)
+
+    def pts(v):
+        if _is_torch(v):
+            h = _Arr(v.to(ah.t.device) if dev else v.cpu().numpy(), dtype=dt)
+        else:
+            v = np.asarray(v, dtype=dt)
+            h = _Arr(torch.as_tensor(v).to(ah.t.device) if dev else v, dtype=dt)
+        n = h.shape[0]
+        cols = int(np.prod(h.shape[1:])) if len(h.shape) > 1 else 1
+        assert cols in (1, ncol), 'xp / fp must have one column or one per column of `at`'
+        return h, n, cols
+    (xh, n, xc), (fh, n2, fc) = pts(xp), pts(fp)
+    assert n == n2, 'xp and fp must have the same number of points'
+    lib = L.init(_device_of(ah))
+    out, optr = _alloc((m, ncol), dt, dev, ah)
+    L.check(lib.xp_interp1d(C.byref(_view(ah, m, ncol)), C.byref(_view(xh, n, xc)), C.byref(_view(fh, n, fc)),
+                            C.c_void_p(optr), _stream(dev)))
+    return out.reshape((m,) + hshape)
+
+
+def add_lcl_to_profile(profile, environment=None, interpolator='log'):
+    """pf.py:858: profile = dict with pressure, temperature, virtual_temperature (nlev, ...) and lcl_pressure,
+    lcl_temperature, lcl_virtual_temperature (...); environment = dict with pressure and variables.  Returns the profile
+    with the LCL inserted as a level (nlev + 1 rows) and, per environment variable k, environment_k with the environment
+    interpolated at the LCL inserted likewise (its virtual temperature recomputed from the interpolated temperature and
+    dewpoint, pf.py:911-920)."""
+    if interpolator not in ('linear', 'log'):
+        raise AssertionError('interpolator must be linear or log')                      # pf.py:878
+    level = {'pressure': profile['lcl_pressure'], 'temperature': profile['lcl_temperature'],
+             'virtual_temperature': profile['lcl_virtual_temperature']}
+    out = insert_level({k: profile[k] for k in level}, level, coords='pressure')
+    for k in ('lcl_pressure', 'lcl_temperature', 'lcl_virtual_temperature'):
+        out[k] = profile[k]
+    if environment is not None:
+        il = {k: interp_level(environment['pressure'], v, level['pressure'], log=(interpolator == 'log'))
+              for k, v in environment.items()}
+        il['pressure'] = level['pressure']
+        if 'virtual_temperature' in il:
+            il['virtual_temperature'] = virtual_temperature(il['temperature'],
+                                                            mixing_ratio(il['temperature'], il['dewpoint'], il['pressure']))
+        env = insert_level(environment, il, coords='pressure')
+        for k in environment.keys():
+            if k != 'pressure':
+                out['environment_' + k] = env[k]
+    return out
 
 
 def freezing_level_height(temperature, height):

@@ -352,21 +352,28 @@ def wet_bulb_temperature(pressure, temperature, dewpoint, vert_dim=VERT, moist=N
                  attrs={'long_name': 'Wet bulb temperature', 'units': 'K'})
 
 
-def log_interp(x, coords, at, dim=VERT):
-    """pf.py:1813 for one DataArray `x`."""
+def _interp(x, coords, at, dim, log, keep_attrs=True):
     cv, dims, hcoords, _ = _split(coords, dim)
-    xv, _, _, _ = _split(x, dim)
-    return _horiz(_np(_api.interp_level(cv, xv, np.asarray(getattr(at, 'values', at)), log=True)), dims, hcoords,
-                  attrs=dict(getattr(x, 'attrs', {})))
+    atv = np.asarray(getattr(at, 'values', at))
+
+    def one(v):
+        xv = _split(v, dim)[0]
+        return _horiz(_np(_api.interp_level(cv, xv, atv, log=log)), dims, hcoords,
+                      attrs=dict(getattr(v, 'attrs', {})) if keep_attrs else {}, name=getattr(v, 'name', None))
+    if isinstance(x, Dataset):                                      # every variable of the dataset (pf.py:82, 896, 901)
+        return Dataset({k: one(x[k]) for k in (list(x.data_vars) if hasattr(x, 'data_vars') else list(x.keys()))})
+    return one(x)
+
+
+def log_interp(x, coords, at, dim=VERT):
+    """pf.py:1813: `x` a DataArray or a Dataset."""
+    return _interp(x, coords, at, dim, log=True)
 
 
 def linear_interp(x, coords, at, dim=VERT, keep_attrs=True, extrapolate=False):
-    """pf.py:1758 for one DataArray `x` (extrapolate=False only)."""
+    """pf.py:1758 (extrapolate=False only): `x` a DataArray or a Dataset."""
     assert not extrapolate, 'extrapolation is not part of the MI355X path'
-    cv, dims, hcoords, _ = _split(coords, dim)
-    xv, _, _, _ = _split(x, dim)
-    return _horiz(_np(_api.interp_level(cv, xv, np.asarray(getattr(at, 'values', at)), log=False)), dims, hcoords,
-                  attrs=dict(getattr(x, 'attrs', {})) if keep_attrs else {})
+    return _interp(x, coords, at, dim, log=False, keep_attrs=keep_attrs)
 
 
 def lifted_index(profile, vert_dim=VERT, description=None, prefix=None):
@@ -572,6 +579,221 @@ def storm_proxies(dat):
                                                                          'units': 'J kg$^{-2}$ g K$^2$ km$^{-1}$ m s$^{-1}$'}
         out[k] = DataArray(np.asarray(v), dims=ref.dims, coords=ref.coords, attrs=attrs, name=k)
     return out
+
+
+
+# -- the reference's array primitives ------------------------------------------------------------------------------------
+# (the CAPE / CIN kernels do not use them -- they stream a column once -- but callers of the reference can)
+def _vars(ds):
+    return list(ds.data_vars) if hasattr(ds, 'data_vars') else list(ds.keys())
+
+
+def _ds_split(ds, vert_dim):
+    """Dataset -> (dict name -> values with vert_dim first, horizontal dims, their coords, vertical coordinate)."""
+    arrs, dims, coords, vc = {}, (), {}, None
+    for k in _vars(ds):
+        v, d, c, vcoord = _split(ds[k], vert_dim)
+        arrs[k] = v
+        if vc is None and vcoord is not None:
+            dims, coords, vc = d, c, vcoord
+    shape = next((v.shape for v in arrs.values() if vc is not None and v.ndim == len(dims) + 1), None)
+    for k, v in arrs.items():                              # variables without the vertical broadcast along it (xarray.broadcast)
+        if shape is not None and v.shape != shape:
+            arrs[k] = np.broadcast_to(v, shape)
+    return arrs, dims, coords, vc
+
+
+def _ds_vert(arrs, vert_dim, vcoord, dims, coords, like=None):
+    return Dataset({k: _vert(_np(v), vert_dim, vcoord, dims, coords, name=k,
+                             attrs=dict(getattr(like[k], 'attrs', {})) if like is not None and k in like else {})
+                    for k, v in arrs.items()})
+
+
+def _per_point(x, dims):
+    """DataArray / scalar on the horizontal dims -> plain array."""
+    if isinstance(x, DataArray):
+        other = tuple(d for d in x.dims if d in dims)
+        return np.asarray(x.transpose(*other).values if other else x.values)
+    return np.asarray(x)
+
+
+def round_to(x, to, dp=2):
+    """pf.py:358."""
+    return np.round(np.round(x / to) * to, dp)
+
+
+def interp1d_numba(at, xp, fp, out=None):
+    """pf.py:23: numpy.interp along the LAST axis of each argument (the reference's gufunc signature
+    (m),(n),(n)->(m)), leading axes broadcast; `out` is the gufunc's optional output array."""
+    at, xp, fp = (np.asarray(getattr(v, 'values', v), dtype=np.float64) for v in (at, xp, fp))
+    lead = np.broadcast_shapes(at.shape[:-1], xp.shape[:-1], fp.shape[:-1])
+    m, n = at.shape[-1], xp.shape[-1]
+    a = np.moveaxis(np.broadcast_to(at, lead + (m,)), -1, 0).reshape(m, -1)
+    shared = xp.ndim == 1
+    x = xp if shared else np.moveaxis(np.broadcast_to(xp, lead + (n,)), -1, 0).reshape(n, -1)
+    f = fp if fp.ndim == 1 else np.moveaxis(np.broadcast_to(fp, lead + (n,)), -1, 0).reshape(n, -1)
+    res = np.moveaxis(_np(_api.interp1d(a, x, f)).reshape((m,) + lead), 0, -1)
+    if out is not None:
+        out[...] = res
+        return out
+    return res
+
+
+def bound_pressure(pressure, bound, vert_dim=VERT):
+    """pf.py:208."""
+    p, dims, coords, _ = _split(pressure, vert_dim)
+    return _horiz(_np(_api.bound_pressure(p, _per_point(bound, dims))), dims, coords, attrs=dict(getattr(pressure, 'attrs', {})),
+                  name=getattr(pressure, 'name', None))
+
+
+def get_layer(dat, depth=100, vert_dim=VERT, interpolate=True):
+    """pf.py:63."""
+    arrs, dims, coords, vc = _ds_split(dat, vert_dim)
+    r = _api.get_layer(arrs, depth=depth, interpolate=interpolate)
+    n = len(vc)
+    vcoord = (np.arange(n + 1) + vc[0]) if interpolate else vc              # insert_level re-indexes (pf.py:971)
+    return _ds_vert(r, vert_dim, vcoord, dims, coords, like=dat)
+
+
+def insert_level(d, level, coords, vert_dim=VERT, fill_value=-999):
+    """pf.py:933."""
+    arrs, dims, hcoords, vc = _ds_split(d, vert_dim)
+    _check_index(vc, 'Vert_dim index increments must all be 1.')                           # pf.py:957
+    assert not np.any(arrs[coords] == fill_value), 'dataset d contains fill_value.'        # pf.py:965
+    lev = {k: np.broadcast_to(_per_point(level[k], dims), arrs[coords].shape[1:]) for k in _vars(level)}
+    r = _api.insert_level(arrs, lev, coords=coords, fill_value=fill_value)
+    return _ds_vert(r, vert_dim, np.arange(len(vc) + 1) + vc[0], dims, hcoords, like=d)
+
+
+def find_intersections(x, a, b, dim, log_x=False):
+    """pf.py:992."""
+    xv, dims, coords, vc = _split(x, dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:1012
+    av, bv = _split(a, dim)[0], _split(b, dim)[0]
+    r = _api.find_intersections(xv, np.broadcast_to(av, xv.shape), np.broadcast_to(bv, xv.shape), log_x=log_x)
+    return _ds_vert(r, 'offset_dim', vc[1:], dims, coords)                                 # pf.py:1062
+
+
+def trapz(dat, x, dim, mask=None, only_positive=False, only_negative=False):
+    """pf.py:164: `dat` a Dataset, `x` the NAME of its x variable; every variable is integrated (x itself included, as
+    in the reference)."""
+    arrs, dims, coords, vc = _ds_split(dat, dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:183
+    assert not (only_positive and only_negative), 'Only negative OR positive regions can be included in trapz.'
+    m = None
+    if mask is not None:
+        m = _split(mask, dim)[0] if isinstance(mask, DataArray) else np.asarray(mask)
+        m = np.broadcast_to(m, (m.shape[0],) + arrs[x].shape[1:])[:len(vc) - 1]            # labels 0 .. n-2 (pf.py:190-195)
+    r = _api.trapz(arrs, arrs[x], mask=m, only_positive=only_positive, only_negative=only_negative)
+    return Dataset({k: _horiz(_np(v), dims, coords, name=k) for k, v in r.items()})
+
+
+def trap_around_zeros(x, y, dim, log_x=True, start=0):
+    """pf.py:1200 (start = 0)."""
+    xv, dims, coords, vc = _split(x, dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:1221
+    areas, mask = _api.trap_around_zeros(xv, _split(y, dim)[0], log_x=log_x, start=start)
+    labels = np.concatenate([vc, vc[1:]])                                                  # pf.py:1273: concat of the two families
+    return (_ds_vert(areas, dim, labels, dims, coords),
+            _vert(_np(mask), dim, vc, dims, coords))
+
+
+def shift_out_nans(x, name, dim):
+    """pf.py:1699."""
+    arrs, dims, coords, vc = _ds_split(x, dim)
+    _check_index(vc, 'Index increments must all be 1.')                                    # pf.py:1712
+    return _ds_vert(_api.shift_out_nans(arrs, name), dim, vc, dims, coords, like=x)
+
+
+def from_most_unstable_parcel(pressure, temperature, dewpoint, vert_dim=VERT, depth=300):
+    """pf.py:1517."""
+    _named(pressure, temperature, dewpoint)
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    rp, rt, rtd, parcel, kept = _api.from_most_unstable_parcel(p, _split(temperature, vert_dim)[0], _split(dewpoint, vert_dim)[0],
+                                                               depth=depth)
+    vcoord = vc[kept]                                                                      # dropna keeps the labels (pf.py:1552)
+    outs = [_vert(_np(v), vert_dim, vcoord, dims, coords, attrs=dict(getattr(src, 'attrs', {})), name=k)
+            for k, v, src in (('pressure', rp, pressure), ('temperature', rt, temperature), ('dewpoint', rtd, dewpoint))]
+    layer = Dataset({k: _horiz(_np(parcel[k]), dims, coords, name=k) for k in ('pressure', 'temperature', 'dewpoint')})
+    return outs[0], outs[1], outs[2], layer
+
+
+def mix_layer(pressure, temperature, dewpoint, vert_dim=VERT, depth=100, load=True):
+    """pf.py:1604."""
+    _named(pressure, temperature, dewpoint)
+    p, dims, coords, vc = _split(pressure, vert_dim)
+    rp, rt, rtd, parcel, kept = _api.mix_layer(p, _split(temperature, vert_dim)[0], _split(dewpoint, vert_dim)[0], depth=depth)
+    surv = vc[kept]
+    vcoord = np.concatenate([[(surv.min() if len(surv) else vc[0]) - 1], surv])            # pf.py:1641
+    outs = [_vert(_np(v), vert_dim, vcoord, dims, coords, attrs=dict(getattr(src, 'attrs', {})), name=k)
+            for k, v, src in (('pressure', rp, pressure), ('temperature', rt, temperature), ('dewpoint', rtd, dewpoint))]
+    mp = Dataset({k: _horiz(_np(parcel[k]), dims, coords, name=k) for k in ('pressure', 'temperature', 'dewpoint')})
+    mp.temperature.attrs.update({'long_name': 'Mixed parcel temperature', 'units': 'K'})
+    mp.dewpoint.attrs.update({'long_name': 'Mixed-parcel dewpoint'})
+    return outs[0], outs[1], outs[2], mp
+
+
+def add_lcl_to_profile(profile, vert_dim=VERT, environment=None, interpolator='log'):
+    """pf.py:858."""
+    assert interpolator in ['linear', 'log'], 'interpolator must be linear or log'         # pf.py:878
+    lev_keys = ('pressure', 'temperature', 'virtual_temperature')
+    p, dims, coords, vc = _split(profile['pressure'], vert_dim)
+    _check_index(vc, 'Vert_dim index increments must all be 1.')
+    prof = {k: _split(profile[k], vert_dim)[0] for k in lev_keys}
+    for k in _LCL_KEYS:
+        prof[k] = _per_point(profile[k], dims)
+    env = None
+    if environment is not None:
+        env = _ds_split(environment, vert_dim)[0]
+    r = _api.add_lcl_to_profile(prof, environment=env, interpolator=interpolator)
+    vcoord = np.arange(len(vc) + 1) + vc[0]
+    out = Dataset()
+    for k, v in r.items():
+        if k in _LCL_KEYS:
+            out[k] = _horiz(_np(v), dims, coords, attrs=dict(_ATTRS[k]), name=k)
+        elif k.startswith('environment_'):
+            out[k] = _vert(_np(v), vert_dim, vcoord, dims, coords, attrs=dict(getattr(environment[k[12:]], 'attrs', {})), name=k)
+        else:
+            out[k] = _vert(_np(v), vert_dim, vcoord, dims, coords, attrs=dict(getattr(profile[k], 'attrs', {})), name=k)
+    out['temperature'].attrs['long_name'] = 'Temperature at LCL'                           # pf.py:889-891 (sic)
+    out['pressure'].attrs['long_name'] = 'Pressure at LCL'
+    out['lcl_virtual_temperature'].attrs['long name'] = 'Virtual temperature at LCL'
+    return out
+
+
+def moist_adiabat_lookup(pressure_levels=np.round(np.arange(1100, 2, step=-0.5), 1),
+                         temperatures=np.round(np.arange(173, 316, step=0.02), 2), pres_step=0.5, temp_step=0.02):
+    """pf.py:447: the two lookup tables as Datasets in the reference's layout -- adiabat_lookup.adiabat(pressure,
+    temperature) = adiabat number (NaN = none) and adiabats.temperature(adiabat, pressure) -- generated on the GPU
+    (adiabat_tables.moist_adiabat_lookup).  Only the reference's default grid is implemented: the device tables are
+    addressed arithmetically on it."""
+    from . import adiabat_tables as at
+    pl, tt = at._grids()
+    assert (np.array_equal(np.asarray(pressure_levels), pl) and np.array_equal(np.asarray(temperatures), tt) and
+            pres_step == at.P_STEP and temp_step == at.T_STEP), 'only the default table grid is implemented'
+    return _table_datasets(*at.moist_adiabat_lookup())
+
+
+def _table_datasets(index, adiabats):
+    from . import adiabat_tables as at
+    pl, tt = at._grids()
+    lookup = Dataset({'adiabat': DataArray(np.where(index == 0, np.nan, index.astype(np.float64)), dims=('pressure', 'temperature'),
+                                           coords={'pressure': pl, 'temperature': tt}, attrs={'long_name': 'Adiabat index'},
+                                           name='adiabat')})
+    curves = Dataset({'temperature': DataArray(np.asarray(adiabats, dtype=np.float64)[:, ::-1], dims=('adiabat', 'pressure'),
+                                               coords={'adiabat': np.arange(1, adiabats.shape[0] + 1), 'pressure': pl},
+                                               attrs={'long_name': 'Temperature', 'units': 'K'}, name='temperature')})
+    return lookup, curves
+
+
+def moist_adiabat_tables(regenerate=False, cache=True, chunks=None, base_dir='.',
+                         lookup_cache='/adiabat_lookups/moist_adiabat_lookup.nc',
+                         adiabats_cache='/adiabat_lookups/adiabats_cache.nc', **kwargs):
+    """pf.py:318: the cached tables, or freshly generated ones.  The cache is one .npz under
+    base_dir/adiabat_lookups/ (NetCDF is not available here; `lookup_cache` / `adiabats_cache` / `chunks` are accepted
+    and ignored); unlike the reference, a missing cache is regenerated instead of failing to open."""
+    from . import adiabat_tables as at
+    return _table_datasets(*at.moist_adiabat_tables(regenerate=regenerate, cache=cache, base_dir=base_dir))
 
 
 # -- tables (pf.py:39-61) ------------------------------------------------------------------------------
