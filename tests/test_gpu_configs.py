@@ -115,3 +115,68 @@ def test_config1_stand_in_through_the_harness():
             assert np.all(np.abs(a - b) <= tol), (name, k, float(np.max(np.abs(a - b))))
     r = xa.cape_cin_columns(p, t, q, humidity='specific')
     _compare(r, ref, np.float32, 1e-6)
+
+
+def test_self_test_leg_of_the_harness_vs_oracle(capsys):
+    """conv_properties_xarray (parcel_test.py:416-547), the vectorised leg of the reference's self-test: every variable
+    it returns against the one-column oracle on a small fp64 grid (exact moist mode -- what the reference's
+    comparison with MetPy is run with); compare / compare_results (pt.py:37-66, 577-584) report nothing for equal
+    sets and a line for a perturbed one."""
+    from oracle import parcel_oracle as po
+    from xarray_parcel_amd import parcel_functions as pf
+    from xarray_parcel_amd import parcel_test as pt
+    from xarray_parcel_amd._xr import DataArray, Dataset
+    nlev, ny, nx = 40, 3, 4
+    lv = 'model_level_number'
+    p, t, td = synth.columns(nlev, ny * nx, seed=77, dtype=np.float64)
+    e = th.saturation_vapor_pressure(td)
+    w = th.EPSILON * e / (p - e)
+    q = w / (1.0 + w)
+
+    def mk(a, n):
+        return DataArray(a.reshape(nlev, ny, nx), dims=(lv, 'latitude', 'longitude'), name=n,
+                         coords={lv: np.arange(nlev), 'latitude': np.arange(ny), 'longitude': np.arange(nx)})
+    dat = Dataset({'pressure': mk(p, 'pressure'), 'temperature': mk(t, 'temperature'), 'specific_humidity': mk(q, 'specific_humidity')})
+    pf.set_moist_lapse('exact')
+    out = pt.conv_properties_xarray(dat, virt_temp=True, lcl_interp='log', pos_cape_neg_cin=True)
+    want = {'dewpoint', 'mp_pressure', 'mp_temperature', 'mp_dewpoint', 'dry_lapse_temp', 'moist_lapse_temp', 'mixed_cape', 'mixed_cin',
+            'max_cape', 'max_cin', 'surf_pres', 'surface_profile', 'surf_temp', 'surface_lcl_pressure', 'surface_lcl_temp',
+            'surface_lfc_pressure', 'surface_lfc_temp', 'surface_el_pressure', 'surface_el_temp', 'surface_cape', 'surface_cin',
+            'lifted_index', 'dci', 'wet_bulb_temperature', 'wet_bulb_temperature_fast'}
+    assert want <= set(out.keys()), want - set(out.keys())
+    assert out['surface_profile'].dims[0] == lv + '_lcl' and out['surface_profile'].shape == (nlev + 1, ny, nx)
+    with np.errstate(all='ignore'):
+        tdr = th.dewpoint_from_specific_humidity(p, t, q)
+    flat = lambda k: np.asarray(out[k].values, dtype=np.float64).reshape(out[k].shape[0], -1) if out[k].ndim == 3 else \
+        np.asarray(out[k].values, dtype=np.float64).reshape(-1)
+    assert np.max(np.abs(flat('dewpoint') - tdr)) <= 1e-10
+    po.set_moist_lapse('rk4')
+    try:
+        per_col = []
+        for c in range(ny * nx):
+            with np.errstate(all='ignore'):
+                sb, sprof = po.surface_based_cape_cin(p[:, c], t[:, c], tdr[:, c])
+                ml, mprof, mp = po.mixed_layer_cape_cin(p[:, c], t[:, c], tdr[:, c], depth=100)
+                mu, _, _ = po.most_unstable_cape_cin(p[:, c], t[:, c], tdr[:, c], depth=300)
+                le = po.lfc_el(sprof['pressure'], sprof['temperature'], sprof['environment_temperature'], sprof['lcl_pressure'],
+                               sprof['lcl_temperature'])
+                li = po.lifted_index(mprof)
+            per_col.append((sb, sprof, ml, mp, mu, le, li))
+    finally:
+        po.set_moist_lapse('ode')
+    for c in range(ny * nx):
+        sb, sprof, ml, mp, mu, le, li = per_col[c]
+        for k, v in (('surface_cape', sb['cape']), ('surface_cin', sb['cin']), ('mixed_cape', ml['cape']), ('mixed_cin', ml['cin']),
+                     ('max_cape', mu['cape']), ('max_cin', mu['cin']), ('mp_temperature', mp['temperature']), ('mp_dewpoint', mp['dewpoint']),
+                     ('surface_lcl_pressure', sprof['lcl_pressure']), ('surface_lfc_pressure', le['lfc_pressure']),
+                     ('surface_el_pressure', le['el_pressure']), ('lifted_index', li)):
+            a = flat(k)[c]
+            assert (np.isnan(a) and np.isnan(v)) or abs(a - v) <= 1e-6 * max(1.0, abs(v)), (k, c, a, v)
+        a, b = flat('surface_profile')[:, c], np.asarray(sprof['temperature'])
+        assert np.allclose(a[:len(b)], b, rtol=0, atol=1e-6, equal_nan=True)
+    capsys.readouterr()
+    pt.compare_results(out, out)
+    assert 'K' not in capsys.readouterr().out.split('\n', 1)[1]               # header only
+    worse = Dataset({'surface_cape': DataArray(out['surface_cape'].values + 1.0, dims=out['surface_cape'].dims, attrs=out['surface_cape'].attrs)})
+    assert pt.compare(worse['surface_cape'], out['surface_cape'], name='surface_cape') is False
+    assert 'surface_cape' in capsys.readouterr().out
