@@ -522,18 +522,29 @@ struct Family {
     // level; the LCL's own Tv - T to begin with).  Three Newton steps reach the 1e-13 K of the five cold ones
     // (5.7e-14 on 50-level columns); a residual test sends coarse columns -- where the offset moved too far -- through two
     // more.  NaN in (missing pressure) leaves `off` alone.
-    XP_DEV static double temperature_from(const double *es, double p, double tv, double &off) {
+    // Only the residual f has to be exact: the slope enters the step alone, so its two reciprocals are the bare v_rcp_f64
+    // (2^-23 relative: the step after a residual of 1e-6 K still lands within 1.2e-13 K) -- 14 instructions less per step.
+    // `all_in_range`: wave-uniform promise that every lane's tv - off lies inside the e_s table (see es_tab).
+    XP_DEV static double temperature_from(const double *es, double p, double tv, double &off, bool all_in_range = false) {
         constexpr double c = VT_EPS * EPS;
         double t = tv - off, f = 0.0;
 #pragma nounroll
         for (int it = 0; it < 3; ++it) {
-            double e = es_tab(es, t);
+            double e = es_tab(es, t, all_in_range);
+#ifdef XP_NEWTON_EXACT_SLOPE
             double rt = frcp(t - 29.65), rp = frcp(p - e);
+#else
+            double rt = __builtin_amdgcn_rcp(t - 29.65), rp = frcp(p - e);
+#endif
             double de = e * (17.67 * 243.5) * (rt * rt);
             double g = c * e * rp;
             f = __builtin_fma(t, g, t) - tv;
             double df = 1.0 + g + t * c * p * de * (rp * rp);
+#ifdef XP_NEWTON_EXACT_SLOPE
             t = t - fdiv(f, df);
+#else
+            t = t - f * __builtin_amdgcn_rcp(df);
+#endif
         }
         // f is the residual BEFORE the last step; quadratic convergence: the step after a residual below 1e-6 K lands within 1e-13
         bool more = !(fabs(f) <= 1e-6);

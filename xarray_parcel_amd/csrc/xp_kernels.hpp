@@ -30,6 +30,7 @@ struct ProfileOut {
     void *v[6];            // p, t_parcel, tv_parcel, t_env, tv_env, td_env (each may be null)
     int64_t nlev_out, ls, cs;
     int f64;
+    int native6;           // all six arrays wanted, in the dtype of the input views: the row is stored without per-array tests
     void *li;              // lifted index (pf.py:1722): environment minus parcel temperature of this profile at exp(li_x) hPa
     double li_x;           // ln of that pressure
 };
@@ -327,12 +328,28 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             if (jout < a.prof.nlev_out) {
                 int64_t o = jout * a.prof.ls + c * a.prof.cs;
                 bool dead = isnan_(P);                                     // NaN-coordinate rows come out all-NaN (pf.py:963, 988)
+#ifndef XP_NO_NATIVE6
+                if (a.prof.native6) {
+                    // the common request (the drivers, BASELINE config 3): six stores of the input dtype, no null / dtype
+                    // test per array (each was two scalar branches plus, at this register pressure, two v_readlane), the
+                    // NaN-row select done on the converted value
+                    const T vP = (T)P;
+                    ((T *)a.prof.v[0])[o] = vP;
+                    ((T *)a.prof.v[1])[o] = dead ? vP : (T)tp;
+                    ((T *)a.prof.v[2])[o] = dead ? vP : (T)tvp;
+                    ((T *)a.prof.v[3])[o] = dead ? vP : (T)te;
+                    ((T *)a.prof.v[4])[o] = dead ? vP : (T)tve;
+                    ((T *)a.prof.v[5])[o] = dead ? vP : (T)tde;
+                } else
+#endif
+                {
                 st(a.prof.v[0], a.prof.f64, o, P);
                 st(a.prof.v[1], a.prof.f64, o, dead ? P : tp);
                 st(a.prof.v[2], a.prof.f64, o, dead ? P : tvp);
                 st(a.prof.v[3], a.prof.f64, o, dead ? P : te);
                 st(a.prof.v[4], a.prof.f64, o, dead ? P : tve);
                 st(a.prof.v[5], a.prof.f64, o, dead ? P : tde);
+                }
             }
             ++jout;
             // lifted_index (pf.py:1722 = log_interp of the profile's two temperatures at one pressure, pf.py:1813): the
@@ -388,21 +405,27 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // one wave-uniform range test per level instead of one per e_s evaluation; the two sides are separate code (the
         // asm barrier keeps the compiler from merging them into one path full of selects)
         constexpr bool PARCEL_ES = TABLE;                                  // exact mode: e_s(T) rides along with the RK4 state
-        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tf, 0.0));
-        double ep = 0.0, we;
+        // (family profile kernels: the parcel's plain temperature is found by Newton steps that evaluate e_s a few kelvin
+        // below its virtual temperature -- same promise, with that margin)
+        constexpr bool FAM_T = FAMILY && PROFILE;
+        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tf, 0.0)) &&
+                              (!FAM_T || in_table(tf, 8.0));
+        double ep = 0.0, we, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
             we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, true);
+            if (FAM_T) tpf = Family::temperature_from(es, P, tf, fam_off, true);
         } else {
             double tq = tf;
             asm volatile("" : "+v"(tq));
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
             we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, false);
+            if (FAM_T) tpf = Family::temperature_from(es, P, tq, fam_off, false);
         }
         double tp, tvp;
         if (FAMILY) {
             tvp = tf;
-            tp = PROFILE ? Family::temperature_from(es, P, tf, fam_off) : !vtc ? Family::temperature_of(es, P, tf) : tf;   // (not used when neither holds)
+            tp = PROFILE ? tpf : !vtc ? Family::temperature_of(es, P, tf) : tf;   // (not used when neither holds)
         } else {
             tp = tf;
             tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                                // pf.py:760

@@ -506,6 +506,9 @@ int xp_cape_cin(const xp_view *p, const xp_view *t, const xp_view *td, const xp_
         for (int v = 0; v < 6; ++v) rows = rows || a.prof.v[v] != nullptr;
         if (!rows) a.prof.nlev_out = 0;                    // lifted index only: the kernel's row loops see an empty profile
         a.prof.f64 = profile->dtype == XP_F64;
+        bool all6 = true;
+        for (int v = 0; v < 6; ++v) all6 = all6 && a.prof.v[v] != nullptr;
+        a.prof.native6 = all6 && profile->dtype == p->dtype;
         if (profile->lifted_index) {
             if (!(profile->lifted_index_pressure > 0.0)) return fail(XP_E_ARG, "profile: lifted_index_pressure must be positive");
             if ((rc = st.out(profile->lifted_index, (size_t)a.ncol * esize(profile->dtype), profile->mem, &a.prof.li))) return rc;
