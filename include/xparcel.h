@@ -309,6 +309,32 @@ typedef struct {
 } xp_conv_out;
 int xp_conv_properties(const xp_conv_in *in, const xp_opts *opts, int32_t ignore_nans, xp_conv_out *out, void *stream);
 
+/* ---- Per-point products on top of the bundle (no parcel lifting: array arithmetic in the reference) --------------------
+   n values each, of `dtype`, in `mem`; flags are int32 0 / 1. */
+
+/* pf.py:2216-2259 wind_shear: the wind at shear_height [m] (linear interpolation in height over the (nwind, ncol) views,
+   pf.py:1758 rule) minus the surface wind; outputs nullable. */
+int xp_wind_shear(const xp_view *wind_u, const xp_view *wind_v, const xp_view *height, const void *surface_wind_u,
+                  const void *surface_wind_v, double shear_height, void *shear_u, void *shear_v, void *shear_magnitude,
+                  int32_t *positive_shear, void *stream);
+
+/* pf.py:2261-2306 significant_hail_parameter (SPC SHIP) with the reference's validity windows. */
+int xp_significant_hail_parameter(int64_t n, int32_t dtype, int32_t mem, const void *mucape, const void *mixing_ratio,
+                                  const void *lapse, const void *temp_500, const void *shear, const void *flh, void *out,
+                                  void *stream);
+
+/* pf.py:2323-2407 storm_proxies from the outputs of xp_conv_properties: nine flags (each nullable) and SHIP. */
+typedef struct {
+    const void *mu_cape, *mu_mixing_ratio, *mixed_100_cape, *mixed_100_cin, *mixed_100_lifted_index, *mixed_100_dci;
+    const void *mixed_50_cape, *mixed_50_cin, *lapse_rate_700_500, *temp_500, *freezing_level, *shear_magnitude;
+    const int32_t *positive_shear;
+} xp_proxies_in;
+typedef struct {
+    int32_t *craven2004, *kunz2007, *trapp2007, *marsh2009, *allen2011, *allen2014, *eccel2012, *mohr2013, *ship_0_1;
+    void *ship;
+} xp_proxies_out;
+int xp_storm_proxies(int64_t n, int32_t dtype, int32_t mem, const xp_proxies_in *in, xp_proxies_out *out, void *stream);
+
 /* ---- Array primitives of the reference's implementation -------------------------------------------------------------
    The CAPE / CIN kernels stream a column once and never build the arrays these functions return, but the reference
    exposes them (and its tests call two of them), so a caller of the reference finds them here too.  One variable per

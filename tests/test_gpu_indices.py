@@ -312,3 +312,58 @@ def test_conv_properties_and_storm_proxies_vs_oracle(xa):
     prox = pf.storm_proxies(props)
     assert prox['proxy_Kunz2007'].attrs['long_name'] == 'Proxy Kunz 2007'
     assert np.array_equal(prox['proxy_SHIP_0.1'].values.astype(bool), np.asarray(gp['proxy_SHIP_0.1']).astype(bool))
+
+
+def test_per_point_product_kernels_vs_oracle(xa):
+    """xp_storm_proxies / xp_significant_hail_parameter / xp_wind_shear (pf.py:2323, 2261, 2216) on inputs that straddle
+    every threshold and validity window (the bundle's own outputs on the synthetic columns rarely do), NaNs included:
+    flags identical, SHIP and shear to the last bits (same operation order, no FMA contraction)."""
+    import torch
+    rng = np.random.default_rng(9)
+    n = 4000
+    d = {'mu_cape': rng.uniform(-200, 4000, n), 'mu_mixing_ratio': rng.uniform(0.008, 0.016, n),
+         'mixed_100_cape': rng.uniform(-100, 3000, n), 'mixed_100_cin': rng.uniform(-120, 5, n),
+         'mixed_100_lifted_index': rng.uniform(-8, 6, n), 'mixed_100_dci': rng.uniform(5, 40, n),
+         'mixed_50_cape': rng.uniform(-100, 3000, n), 'mixed_50_cin': rng.uniform(-60, 5, n),
+         'lapse_rate_700_500': rng.uniform(-9, -4, n), 'temp_500': rng.uniform(245, 275, n),
+         'freezing_level': rng.uniform(500, 5000, n), 'shear_magnitude': rng.uniform(0, 40, n),
+         'positive_shear': rng.random(n) < 0.6}
+    for i, k in enumerate(k for k in d if k != 'positive_shear'):
+        d[k][i::53] = np.nan
+    got = xa.storm_proxies(d)
+    ref = po.storm_proxies(d)
+    assert list(got) == list(ref)                                      # the reference's order of variables
+    for k in ref:
+        if k == 'ship':
+            assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])) and np.isfinite(ref[k]).sum() > 100
+            assert np.nanmax(np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)) <= 4e-16
+        else:
+            assert got[k].dtype == bool and np.array_equal(got[k], ref[k]), k
+            assert 0 < ref[k].sum() < n, k                             # both outcomes occur
+    ship = xa.significant_hail_parameter(d['mu_cape'], d['mu_mixing_ratio'], d['lapse_rate_700_500'], d['temp_500'],
+                                         d['shear_magnitude'], d['freezing_level'])
+    with np.errstate(invalid='ignore'):
+        r = po.significant_hail_parameter(d['mu_cape'], d['mu_mixing_ratio'], d['lapse_rate_700_500'], d['temp_500'],
+                                          d['shear_magnitude'], d['freezing_level'])
+    assert np.array_equal(np.isnan(ship), np.isnan(r)) and np.nanmax(np.abs(ship - r) / np.maximum(np.abs(r), 1e-300)) <= 4e-16
+    # device tensors, fp32
+    dt_ = {k: torch.as_tensor(v.astype(np.float32) if v.dtype != bool else v).cuda() for k, v in d.items()}
+    g32 = xa.storm_proxies(dt_)
+    assert g32['ship'].is_cuda and g32['ship'].dtype == torch.float32 and g32['proxy_Craven2004'].dtype == torch.bool
+    r32 = po.storm_proxies({k: (v.astype(np.float32).astype(np.float64) if v.dtype != bool else v) for k, v in d.items()})
+    assert (g32['proxy_Marsh2009'].cpu().numpy() != r32['proxy_Marsh2009']).sum() == 0
+    # wind shear: (nwind, ncol) winds on their own heights
+    nw, ncol = 9, 500
+    h = np.sort(rng.uniform(10, 9000, (nw, ncol)), axis=0)
+    h[3, ::7] = 6000.0                                                  # a level exactly at the shear height
+    u, v = rng.normal(0, 12, (nw, ncol)), rng.normal(0, 12, (nw, ncol))
+    u[2, ::11] = np.nan
+    su, sv = rng.normal(0, 5, ncol), rng.normal(0, 5, ncol)
+    gs = xa.wind_shear(su, sv, u, v, h)
+    with np.errstate(invalid='ignore'):
+        rs = [po.wind_shear(su[c], sv[c], u[:, c], v[:, c], h[:, c]) for c in range(ncol)]
+    for k in ('shear_u', 'shear_v', 'shear_magnitude'):
+        r = np.array([x[k] for x in rs])
+        assert np.array_equal(np.isnan(gs[k]), np.isnan(r)) and np.nanmax(np.abs(gs[k] - r)) <= 1e-12, k
+    assert np.array_equal(gs['positive_shear'], np.array([x['positive_shear'] for x in rs]))
+    assert gs['positive_shear'].dtype == bool

@@ -25,6 +25,7 @@ SYMBOLS = ('xp_version', 'xp_init', 'xp_set_tables', 'xp_tables_loaded', 'xp_fam
            'xp_mixed_layer', 'xp_wet_bulb_temperature', 'xp_interp_level', 'xp_interp_levels', 'xp_dewpoint_from_specific_humidity',
            'xp_crossing_level', 'xp_mixing_ratio', 'xp_conv_properties', 'xp_insert_level', 'xp_find_intersections', 'xp_trapz',
            'xp_trap_around_zeros', 'xp_bound_pressure', 'xp_get_layer', 'xp_shift_out_nans', 'xp_rebase_profile', 'xp_interp1d',
+           'xp_wind_shear', 'xp_significant_hail_parameter', 'xp_storm_proxies',
            'xp_last_error')
 
 
@@ -78,6 +79,20 @@ class ConvIn(C.Structure):
 
 class ConvOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in CONV_OUT]
+
+
+PROXIES_IN = ('mu_cape', 'mu_mixing_ratio', 'mixed_100_cape', 'mixed_100_cin', 'mixed_100_lifted_index', 'mixed_100_dci',
+              'mixed_50_cape', 'mixed_50_cin', 'lapse_rate_700_500', 'temp_500', 'freezing_level', 'shear_magnitude')
+PROXIES_OUT = ('proxy_Craven2004', 'proxy_Kunz2007', 'proxy_Trapp2007', 'proxy_Marsh2009', 'proxy_Allen2011', 'proxy_Allen2014',
+               'proxy_Eccel2012', 'proxy_Mohr2013', 'proxy_SHIP_0.1')
+
+
+class ProxiesIn(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in PROXIES_IN] + [('positive_shear', C.c_void_p)]
+
+
+class ProxiesOut(C.Structure):
+    _fields_ = [('f%d' % i, C.c_void_p) for i in range(9)] + [('ship', C.c_void_p)]
 
 
 class Tables(C.Structure):

@@ -12,6 +12,7 @@
 // Per value the arithmetic is that of the stand-alone kernels (k_dewpoint_from_q, k_interp_levels, k_crossing_level).
 #pragma once
 #include "xp_kernels.hpp"
+#include "xp_primitives.hpp"   // interp_column
 
 namespace xp {
 
@@ -158,6 +159,91 @@ template <typename T> __global__ __launch_bounds__(256) void k_conv_finish(ConvF
     const double du = hu - su, dv = hv - sv;
     put(a.shear_u, du); put(a.shear_v, dv); put(a.shear_mag, sqrt(du * du + dv * dv));
     a.positive_shear[c] = (keep && sqrt(hu * hu + hv * hv) > sqrt(su * su + sv * sv)) ? 1 : 0;
+}
+
+
+// ---- per-point products on top of the bundle -----------------------------------------------------------------------------
+// significant_hail_parameter (pf.py:2261-2306, SPC SHIP) in the reference's operation order
+XP_DEV double ship_value(double mucape, double mixing_ratio, double lapse, double temp_500, double shear, double flh) {
+#pragma clang fp contract(off)
+    mixing_ratio = mixing_ratio * 1e3;                                      // kg/kg -> g/kg
+    lapse = -lapse;
+    temp_500 = temp_500 - 273.15;
+    shear = (shear >= 7.0 && shear <= 27.0) ? shear : qnan();               // validity windows (pf.py:2287-2289)
+    mixing_ratio = (mixing_ratio >= 11.0 && mixing_ratio <= 13.6) ? mixing_ratio : qnan();
+    temp_500 = (temp_500 <= -5.5) ? temp_500 : -5.5;
+    double ship = mucape * mixing_ratio * lapse * -temp_500 * shear / 42000000.0;
+    ship = (mucape >= 1300.0) ? ship : ship * (mucape / 1300.0);
+    ship = (lapse >= 5.8) ? ship : ship * (lapse / 5.8);
+    ship = (flh >= 2400.0) ? ship : ship * (flh / 2400.0);
+    return ship;
+}
+template <typename T> __global__ __launch_bounds__(256)
+void k_ship(int64_t n, const void *mucape, const void *mixing_ratio, const void *lapse, const void *temp_500, const void *shear,
+            const void *flh, void *out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    st(out, sizeof(T) == 8, c, ship_value(ld1<T>(mucape, c), ld1<T>(mixing_ratio, c), ld1<T>(lapse, c), ld1<T>(temp_500, c),
+                                          ld1<T>(shear, c), ld1<T>(flh, c)));
+}
+
+// storm_proxies (pf.py:2323-2407): the nine hail / storm proxies and SHIP from the bundle's per-point values.  Comparisons
+// with NaN are false, as in NumPy.
+struct ProxiesArgs {
+    int64_t n;
+    const void *mu_cape, *mu_mixing_ratio, *mixed_100_cape, *mixed_100_cin, *mixed_100_lifted_index, *mixed_100_dci,
+               *mixed_50_cape, *mixed_50_cin, *lapse_rate_700_500, *temp_500, *freezing_level, *shear_magnitude;
+    const int32_t *positive_shear;
+    int32_t *proxy[9];   // Craven2004, Kunz2007, Trapp2007, Marsh2009, Allen2011, Allen2014, Eccel2012, Mohr2013, SHIP_0.1
+    void *ship;
+};
+template <typename T> __global__ __launch_bounds__(256) void k_storm_proxies(ProxiesArgs a) {
+#pragma clang fp contract(off)
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n) return;
+    const double s06 = ld1<T>(a.shear_magnitude, c);
+    double c100 = ld1<T>(a.mixed_100_cape, c), c50 = ld1<T>(a.mixed_50_cape, c), mucape = ld1<T>(a.mu_cape, c);
+    c100 = (c100 >= 0.0) ? c100 : qnan(); c50 = (c50 >= 0.0) ? c50 : qnan(); mucape = (mucape >= 0.0) ? mucape : qnan();   // pf.py:2340-2343
+    const double li100 = ld1<T>(a.mixed_100_lifted_index, c), dci100 = ld1<T>(a.mixed_100_dci, c);
+    const double cin100 = ld1<T>(a.mixed_100_cin, c), cin50 = ld1<T>(a.mixed_50_cin, c), lapse = ld1<T>(a.lapse_rate_700_500, c);
+    const bool pos = a.positive_shear[c] != 0;
+    const double cs = c100 * s06;
+    const bool allen11 = c50 * pow(s06, 1.67) >= 25000.0;
+    const double ship = ship_value(mucape, ld1<T>(a.mu_mixing_ratio, c), lapse, ld1<T>(a.temp_500, c), s06, ld1<T>(a.freezing_level, c));
+    const bool px[9] = {cs >= 20000.0,
+                        (li100 <= -2.07) || (mucape >= 1474.0) || (dci100 >= 25.7),
+                        (cs >= 10000.0) && (c100 >= 100.0) && (s06 >= 5.0) && pos,
+                        cs >= 10000.0,
+                        allen11,
+                        allen11 && (cin50 > -25.0) && (s06 > 7.5) && (lapse < -6.5),
+                        (cs > 10000.0) && (cin100 > -50.0),
+                        (li100 <= -1.6) || (c100 >= 439.0) || (dci100 >= 26.4),
+                        ship > 0.1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sti(a.proxy[i], c, px[i] ? 1 : 0);
+    st(a.ship, sizeof(T) == 8, c, ship);
+}
+
+// wind_shear (pf.py:2216-2259): the wind at `shear_height` (linear interpolation in height, pf.py:1758 rule) minus the surface wind
+struct ShearArgs {
+    View u, v, h;
+    int64_t nwind, ncol;
+    const void *sfc_u, *sfc_v;
+    double shear_height;
+    void *shear_u, *shear_v, *shear_mag;
+    int32_t *positive_shear;
+};
+template <typename T> __global__ __launch_bounds__(256) void k_wind_shear(ShearArgs a) {
+#pragma clang fp contract(off)
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ncol) return;
+    constexpr int f64 = sizeof(T) == 8;
+    const double hu = interp_column<T>(a.h, a.u, a.nwind, c, a.shear_height, false);
+    const double hv = interp_column<T>(a.h, a.v, a.nwind, c, a.shear_height, false);
+    const double su = ld1<T>(a.sfc_u, c), sv = ld1<T>(a.sfc_v, c);
+    const double du = hu - su, dv = hv - sv;
+    st(a.shear_u, f64, c, du); st(a.shear_v, f64, c, dv); st(a.shear_mag, f64, c, sqrt(du * du + dv * dv));
+    sti(a.positive_shear, c, (sqrt(hu * hu + hv * hv) > sqrt(su * su + sv * sv)) ? 1 : 0);
 }
 
 }  // namespace xp

@@ -223,4 +223,91 @@ int xp_interp1d(const xp_view *at, const xp_view *xp_, const xp_view *fp, void *
     return st.finish();
 }
 
+
+// ---- per-point products on top of the bundle (kernels: xp_bundle.hpp) -------------------------------------------------------
+int xp_wind_shear(const xp_view *wind_u, const xp_view *wind_v, const xp_view *height, const void *surface_wind_u,
+                  const void *surface_wind_v, double shear_height, void *shear_u, void *shear_v, void *shear_magnitude,
+                  int32_t *positive_shear, void *stream) {
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if ((rc = check_view(wind_u, "wind_u")) || (rc = check_view(wind_v, "wind_v")) || (rc = check_view(height, "height")) ||
+        (rc = same_shape(wind_u, wind_v, "wind_u/wind_v")) || (rc = same_shape(wind_u, height, "wind_u/height"))) return rc;
+    if (!surface_wind_u || !surface_wind_v) return fail(XP_E_ARG, "xp_wind_shear: null surface wind");
+    Stager st(stream);
+    xp::ShearArgs a;
+    memset(&a, 0, sizeof(a));
+    const size_t cb = rows_bytes(wind_u, 1);
+    void *pos = nullptr;
+    if ((rc = stage_view(st, wind_u, &a.u)) || (rc = stage_view(st, wind_v, &a.v)) || (rc = stage_view(st, height, &a.h)) ||
+        (rc = st.in(surface_wind_u, cb, wind_u->mem, &a.sfc_u)) || (rc = st.in(surface_wind_v, cb, wind_u->mem, &a.sfc_v)) ||
+        (rc = st.out(shear_u, cb, wind_u->mem, &a.shear_u)) || (rc = st.out(shear_v, cb, wind_u->mem, &a.shear_v)) ||
+        (rc = st.out(shear_magnitude, cb, wind_u->mem, &a.shear_mag)) ||
+        (rc = st.out(positive_shear, (size_t)wind_u->ncol * 4, wind_u->mem, &pos))) return rc;
+    a.positive_shear = (int32_t *)pos;
+    a.nwind = wind_u->nlev; a.ncol = wind_u->ncol; a.shear_height = shear_height;
+    XP_LAUNCH_T(wind_u, wind_u->ncol, st, k_wind_shear, a);
+    return st.finish();
+}
+
+int xp_significant_hail_parameter(int64_t n, int32_t dtype, int32_t mem, const void *mucape, const void *mixing_ratio,
+                                  const void *lapse, const void *temp_500, const void *shear, const void *flh, void *out,
+                                  void *stream) {
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n < 0 || (dtype != XP_F32 && dtype != XP_F64)) return fail(XP_E_ARG, "xp_significant_hail_parameter: bad n / dtype");
+    if (!mucape || !mixing_ratio || !lapse || !temp_500 || !shear || !flh || !out) return fail(XP_E_ARG, "xp_significant_hail_parameter: null argument");
+    Stager st(stream);
+    const size_t b = (size_t)n * esize(dtype);
+    const void *in[6];
+    const void *src[6] = {mucape, mixing_ratio, lapse, temp_500, shear, flh};
+    void *od;
+    for (int i = 0; i < 6; ++i) if ((rc = st.in(src[i], b, mem, &in[i]))) return rc;
+    if ((rc = st.out(out, b, mem, &od))) return rc;
+    if (n) {
+        if (dtype == XP_F64) hipLaunchKernelGGL((xp::k_ship<double>), dim3(blocks(n)), dim3(256), 0, st.s, n, in[0], in[1], in[2], in[3], in[4], in[5], od);
+        else hipLaunchKernelGGL((xp::k_ship<float>), dim3(blocks(n)), dim3(256), 0, st.s, n, in[0], in[1], in[2], in[3], in[4], in[5], od);
+    }
+    return st.finish();
+}
+
+int xp_storm_proxies(int64_t n, int32_t dtype, int32_t mem, const xp_proxies_in *in, xp_proxies_out *out, void *stream) {
+    DevGuard dg_;
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n < 0 || (dtype != XP_F32 && dtype != XP_F64)) return fail(XP_E_ARG, "xp_storm_proxies: bad n / dtype");
+    if (!in || !out) return fail(XP_E_ARG, "xp_storm_proxies: null argument");
+    const void *src[12] = {in->mu_cape, in->mu_mixing_ratio, in->mixed_100_cape, in->mixed_100_cin, in->mixed_100_lifted_index,
+                           in->mixed_100_dci, in->mixed_50_cape, in->mixed_50_cin, in->lapse_rate_700_500, in->temp_500,
+                           in->freezing_level, in->shear_magnitude};
+    for (int i = 0; i < 12; ++i) if (!src[i]) return fail(XP_E_ARG, "xp_storm_proxies: null input %d", i);
+    if (!in->positive_shear) return fail(XP_E_ARG, "xp_storm_proxies: null positive_shear");
+    Stager st(stream);
+    xp::ProxiesArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    const size_t b = (size_t)n * esize(dtype);
+    const void **dst[12] = {&a.mu_cape, &a.mu_mixing_ratio, &a.mixed_100_cape, &a.mixed_100_cin, &a.mixed_100_lifted_index,
+                            &a.mixed_100_dci, &a.mixed_50_cape, &a.mixed_50_cin, &a.lapse_rate_700_500, &a.temp_500,
+                            &a.freezing_level, &a.shear_magnitude};
+    for (int i = 0; i < 12; ++i) if ((rc = st.in(src[i], b, mem, dst[i]))) return rc;
+    const void *ps;
+    if ((rc = st.in(in->positive_shear, (size_t)n * 4, mem, &ps))) return rc;
+    a.positive_shear = (const int32_t *)ps;
+    int32_t *flags[9] = {out->craven2004, out->kunz2007, out->trapp2007, out->marsh2009, out->allen2011, out->allen2014,
+                         out->eccel2012, out->mohr2013, out->ship_0_1};
+    for (int i = 0; i < 9; ++i) {
+        void *d;
+        if ((rc = st.out(flags[i], (size_t)n * 4, mem, &d))) return rc;
+        a.proxy[i] = (int32_t *)d;
+    }
+    if ((rc = st.out(out->ship, b, mem, &a.ship))) return rc;
+    if (n) {
+        if (dtype == XP_F64) hipLaunchKernelGGL((xp::k_storm_proxies<double>), dim3(blocks(n)), dim3(256), 0, st.s, a);
+        else hipLaunchKernelGGL((xp::k_storm_proxies<float>), dim3(blocks(n)), dim3(256), 0, st.s, a);
+    }
+    return st.finish();
+}
+
 }  // extern "C"

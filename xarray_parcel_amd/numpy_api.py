@@ -833,30 +833,41 @@ def _where(c, a, b):
     return np.where(c, a, b)
 
 
+def _flat(hs):
+    n = int(np.prod(hs[0].shape)) if hs[0].shape else 1
+    assert all((int(np.prod(h.shape)) if h.shape else 1) == n for h in hs), 'per-point arguments must share a shape'
+    return n
+
+
+def _as_bool(x):
+    return (x != 0)
+
+
 def wind_shear(surface_wind_u, surface_wind_v, wind_u, wind_v, height, shear_height=6000):
-    """pf.py:2216: wind at `shear_height` (linear interpolation in height) minus the surface wind."""
-    hi_u = interp_level(height, wind_u, float(shear_height), log=False)
-    hi_v = interp_level(height, wind_v, float(shear_height), log=False)
-    shear_u, shear_v = hi_u - surface_wind_u, hi_v - surface_wind_v
-    xp = _ns(shear_u)
-    return {'shear_u': shear_u, 'shear_v': shear_v, 'shear_magnitude': xp.sqrt(shear_u ** 2 + shear_v ** 2),
-            'positive_shear': xp.sqrt(hi_u ** 2 + hi_v ** 2) > xp.sqrt(surface_wind_u ** 2 + surface_wind_v ** 2)}
+    """pf.py:2216: wind at `shear_height` (linear interpolation in height) minus the surface wind (xp_wind_shear)."""
+    (wu, wv, hh), dt, dev = _common(wind_u, wind_v, height)
+    assert wu.shape == wv.shape == hh.shape, 'wind_u, wind_v, height must share a shape'
+    nw, ncol, hshape = _vert_shape(wu)
+    lib = L.init(_device_of(wu))
+    su, sv = _per_col(surface_wind_u, ncol, dt, dev, wu), _per_col(surface_wind_v, ncol, dt, dev, wu)
+    outs = [_alloc((ncol,), dt, dev, wu) for _ in range(3)]
+    pos, pptr = _alloc((ncol,), np.int32, dev, wu)
+    L.check(lib.xp_wind_shear(C.byref(_view(wu, nw, ncol)), C.byref(_view(wv, nw, ncol)), C.byref(_view(hh, nw, ncol)),
+                              C.c_void_p(su.ptr), C.c_void_p(sv.ptr), C.c_double(float(shear_height)), C.c_void_p(outs[0][1]),
+                              C.c_void_p(outs[1][1]), C.c_void_p(outs[2][1]), C.c_void_p(pptr), _stream(dev)))
+    return {'shear_u': outs[0][0].reshape(hshape), 'shear_v': outs[1][0].reshape(hshape),
+            'shear_magnitude': outs[2][0].reshape(hshape), 'positive_shear': _as_bool(pos).reshape(hshape)}
 
 
 def significant_hail_parameter(mucape, mixing_ratio, lapse, temp_500, shear, flh):
-    """pf.py:2261 (SPC SHIP): array arithmetic with the reference's validity windows."""
-    nan = float('nan')
-    mixing_ratio = mixing_ratio * 1e3
-    lapse = -lapse
-    temp_500 = temp_500 - 273.15
-    shear = _where((shear >= 7) & (shear <= 27), shear, nan)
-    mixing_ratio = _where((mixing_ratio >= 11) & (mixing_ratio <= 13.6), mixing_ratio, nan)
-    temp_500 = _where(temp_500 <= -5.5, temp_500, -5.5)
-    ship = mucape * mixing_ratio * lapse * -temp_500 * shear / 42000000
-    ship = _where(mucape >= 1300, ship, ship * (mucape / 1300))
-    ship = _where(lapse >= 5.8, ship, ship * (lapse / 5.8))
-    ship = _where(flh >= 2400, ship, ship * (flh / 2400))
-    return ship
+    """pf.py:2261 (SPC SHIP) with the reference's validity windows (xp_significant_hail_parameter)."""
+    hs, dt, dev = _common(mucape, mixing_ratio, lapse, temp_500, shear, flh)
+    n = _flat(hs)
+    lib = L.init(_device_of(hs[0]))
+    out, optr = _alloc((n,), dt, dev, hs[0])
+    L.check(lib.xp_significant_hail_parameter(C.c_int64(n), C.c_int32(hs[0].xp_dtype), C.c_int32(hs[0].mem),
+                                              *[C.c_void_p(h.ptr) for h in hs], C.c_void_p(optr), _stream(dev)))
+    return out.reshape(hs[0].shape)
 
 
 def conv_properties(dat, ignore_nans=False, moist=None):
@@ -962,26 +973,32 @@ def min_conv_properties(dat, moist=None):
 
 
 def storm_proxies(dat):
-    """pf.py:2323: hail / storm proxies (booleans) and SHIP from the output of conv_properties()."""
-    nan = float('nan')
-    s06 = dat['shear_magnitude']
-    c100 = _where(dat['mixed_100_cape'] >= 0, dat['mixed_100_cape'], nan)
-    c50 = _where(dat['mixed_50_cape'] >= 0, dat['mixed_50_cape'], nan)
-    mucape = _where(dat['mu_cape'] >= 0, dat['mu_cape'], nan)
-    out = {}
-    out['proxy_Craven2004'] = (c100 * s06) >= 20000
-    out['proxy_Kunz2007'] = (dat['mixed_100_lifted_index'] <= -2.07) | (mucape >= 1474) | (dat['mixed_100_dci'] >= 25.7)
-    out['proxy_Trapp2007'] = ((c100 * s06 >= 10000) & (c100 >= 100) & (s06 >= 5)) & dat['positive_shear']
-    out['proxy_Marsh2009'] = (c100 * s06) >= 10000
-    out['proxy_Allen2011'] = c50 * s06 ** 1.67 >= 25000
-    out['proxy_Allen2014'] = (out['proxy_Allen2011'] & (dat['mixed_50_cin'] > -25) & (s06 > 7.5) &
-                              (dat['lapse_rate_700_500'] < -6.5))
-    out['proxy_Eccel2012'] = (c100 * s06 > 10000) & (dat['mixed_100_cin'] > -50)
-    out['proxy_Mohr2013'] = (dat['mixed_100_lifted_index'] <= -1.6) | (c100 >= 439) | (dat['mixed_100_dci'] >= 26.4)
-    out['ship'] = significant_hail_parameter(mucape, dat['mu_mixing_ratio'], dat['lapse_rate_700_500'], dat['temp_500'],
-                                             s06, dat['freezing_level'])
-    out['proxy_SHIP_0.1'] = out['ship'] > 0.1
-    return out
+    """pf.py:2323: hail / storm proxies (booleans) and SHIP from the output of conv_properties(), one per-point kernel
+    (xp_storm_proxies)."""
+    hs, dt, dev = _common(*[dat[k] for k in L.PROXIES_IN])
+    n = _flat(hs)
+    shape = hs[0].shape
+    lib = L.init(_device_of(hs[0]))
+    ps = dat['positive_shear']
+    if _is_torch(ps):
+        ps = ps.to(torch.int32)
+        ps = ps.to(hs[0].t.device) if dev else ps.cpu().numpy()
+    else:
+        ps = np.asarray(ps).astype(np.int32)
+        if dev:
+            ps = torch.as_tensor(ps).to(hs[0].t.device)
+    ps = ps.reshape(-1).contiguous() if _is_torch(ps) else np.ascontiguousarray(ps.reshape(-1))
+    assert int(np.prod(ps.shape)) == n, 'positive_shear does not match the other arrays'
+    pin = L.ProxiesIn(*[h.ptr for h in hs], ps.data_ptr() if _is_torch(ps) else ps.ctypes.data)
+    flags = [_alloc((n,), np.int32, dev, hs[0]) for _ in L.PROXIES_OUT]
+    ship, sptr = _alloc((n,), dt, dev, hs[0])
+    pout = L.ProxiesOut(*[f[1] for f in flags], sptr)
+    L.check(lib.xp_storm_proxies(C.c_int64(n), C.c_int32(hs[0].xp_dtype), C.c_int32(hs[0].mem), C.byref(pin), C.byref(pout),
+                                 _stream(dev)))
+    out = {k: _as_bool(f[0]).reshape(shape) for k, f in zip(L.PROXIES_OUT, flags)}
+    out['ship'] = ship.reshape(shape)
+    # the reference's order of variables (pf.py:2395-2405): proxies, SHIP, the SHIP proxy
+    return {**{k: out[k] for k in L.PROXIES_OUT[:8]}, 'ship': out['ship'], 'proxy_SHIP_0.1': out['proxy_SHIP_0.1']}
 
 
 def family_table():
