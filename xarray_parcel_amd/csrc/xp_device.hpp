@@ -199,6 +199,17 @@ XP_DEV double es_tab(const double *tb, double t, bool all_in_range = false) {
     return p;
 }
 XP_DEV bool in_table(double t, double margin) { return (t >= ES_T_LO + margin) && (t < ES_T_LO + (double)ES_N - margin); }
+// The same test with margin 0 for the per-level code, on the HIGH WORD of the double: both table edges (137 and 330) are
+// integers, so their low words are zero and  lo <= t < hi  <=>  hi32(t) - hi32(lo) < hi32(hi) - hi32(lo)  as unsigned
+// numbers (a negative or NaN t has a huge high word).  One subtraction per value, the values of a level combined with
+// a max, one compare in all -- instead of two fp64 compares, their literals and the mask logic per value.
+constexpr unsigned hi32_of(double x) { return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32); }
+constexpr unsigned ES_HI_LO = hi32_of(ES_T_LO), ES_HI_SPAN = hi32_of(ES_T_LO + (double)ES_N) - hi32_of(ES_T_LO);
+static_assert((__builtin_bit_cast(unsigned long long, ES_T_LO) & 0xffffffffull) == 0 &&
+              (__builtin_bit_cast(unsigned long long, ES_T_LO + (double)ES_N) & 0xffffffffull) == 0, "table edges must have zero low words");
+XP_DEV unsigned table_dist(double t) { return (unsigned)__double2hiint(t) - ES_HI_LO; }     // < ES_HI_SPAN: inside the table
+XP_DEV bool all_in_table(unsigned d) { return d < ES_HI_SPAN; }
+XP_DEV unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
 // ln(x) from the LDS table that follows the e_s table: x = 2^e m, m in [0.5,1) = c_i (1 + r), |r| < 2^-7;
 // ln x = e ln2 + ln c_i + log1p(r), log1p by its series to r^7 (< 2e-18).  Positive finite x (NaN -> NaN).
 // SHORT: log1p(r) through r^5 (|r| <= 2^-7: the next term, r^6 / 6, is 3.6e-14 -- 5e-15 of ln p).  For the ln p of the
@@ -844,7 +855,13 @@ struct Scan {
         bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
         double a = fabs(X - Xp) * ((yp + y) * 0.5);                         // pf.py:186-198
         add(same ? a : 0.0);
+#ifdef XP_NODE_BALLOT
         if (__builtin_amdgcn_ballot_w64(!same) != 0ull && !same) special<LEAN, ABOVE>(X, par, env, y, a);
+#else
+        // (a plain divergent branch: s_and_saveexec + s_cbranch_execz skip it when no lane needs it; the explicit ballot in
+        // front of it cost five instructions per node to rebuild a mask the comparison had already produced)
+        if (!same) special<LEAN, ABOVE>(X, par, env, y, a);
+#endif
         pos_parcel = pos_parcel || ((ABOVE || P < p_lcl) && par > env);     // pf.py:1166-1169 (ABOVE: a NaN pressure comes with a NaN parcel)
         if (!LEAN) {                                                        // status bits (LEAN: the caller did not ask for `status`)
             bad_p = bad_p || (X > Xp);                                      // NaN compares false: a missing pressure is not "bad"

@@ -230,12 +230,16 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // allocator (the dewpoint-input surface kernel of modes 0 / 1 lands below 128 VGPRs on its own and is allocated worse
     // when forced); tests/test_kernel_resources.py checks what comes out.
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
-    __shared__ double s_es[LDS_TAB];
+    // One LDS object with the e_s / ln table FIRST: at LDS address 0 the table base folds into the immediate offsets of the
+    // ds_read instructions (the table is read ~15 times per level; behind the slots every access paid a v_mov for the base).
+    struct Lds { double es[LDS_TAB]; double fam[FAMILY ? FAM_SIZE : 1]; double slot[SLOT_FIELDS * SLOT_STRIDE]; int next; };
+    __shared__ Lds lds;
+    double *const s_es = lds.es;
     // family mode: the coefficient table lives in LDS too (46.7 KB; read 81 doubles at a time by lanes that differ only in
     // their psi-piece: broadcast + adjacent banks, conflict-free, ~100 cycles instead of an L2 round trip per batch)
-    __shared__ double s_fam[FAMILY ? FAM_SIZE : 1];
+    double *const s_fam = lds.fam;
     if (FAMILY) for (int i = threadIdx.x; i < FAM_SIZE; i += blockDim.x) s_fam[i] = a.fam_tab[i];
-    __shared__ int s_next;                                                 // PERSIST: the workgroup's next tile
+    int &s_next = lds.next;                                                // PERSIST: the workgroup's next tile
     if (PERSIST && threadIdx.x == 0) s_next = (int)(blockDim.x >> 6);
     // PERSIST (family mode, large grids; the host decides): the grid is one workgroup per CU, the tables are staged once,
     // and every wavefront takes 64-column tiles from an atomic counter until the grid is done -- no staging and no drain
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         if (!persist && c0 >= a.ncol) return;
     }
     const double *es = s_es;
-    __shared__ double s_slot[SLOT_FIELDS * SLOT_STRIDE];
+    double *const s_slot = lds.slot;
 
     auto column = [&](const int64_t c) __attribute__((always_inline)) {
     Parcel pc;
@@ -408,8 +412,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // (family profile kernels: the parcel's plain temperature is found by Newton steps that evaluate e_s a few kelvin
         // below its virtual temperature -- same promise, with that margin)
         constexpr bool FAM_T = FAMILY && PROFILE;
-        const bool in_range = in_table(T_, 0.0) && (Q || in_table(m_, 0.0)) && (!(PARCEL_ES && need_w) || in_table(tf, 0.0)) &&
-                              (!FAM_T || in_table(tf, 8.0));
+        unsigned dist = table_dist(T_);
+        if (!Q) dist = umax_(dist, table_dist(m_));
+        if (PARCEL_ES && need_w) dist = umax_(dist, table_dist(tf));
+        const bool in_range = all_in_table(dist) && (!FAM_T || in_table(tf, 8.0));
         double ep = 0.0, we, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             tp = m.at(P, X, a.tb);
             tvp = need_w ? virt(tp, mix_of_e(TABLE ? es_tab(es, tp) : m.e, P)) : tp;
         }
-        if (__builtin_amdgcn_ballot_w64(cross) != 0ull && cross) {          // this lane's node is its LCL
+        if (cross) {                                                       // (a plain divergent branch: saveexec + execz)          // this lane's node is its LCL
             double te, tde;
             lcl_environment(P, X, T_, Td_, te, tde);
             // without profile output the scan only sees the temperature picked by the correction switch, which sits in
@@ -483,17 +489,17 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         }
         double tve = T_;                                                   // pf.py:839-843, 911-920
         if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
-            if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
+            if (__builtin_amdgcn_ballot_w64(!all_in_table(umax_(table_dist(T_), table_dist(Td_)))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
             else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
         }
         // For a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at the LCL node is rounding
         // noise of exactly the reference's expressions: those columns evaluate them in its operation order.
         const bool tie = need_w && cross && (l.p == pc.p);
-        if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = T_; asm volatile("" : "+v"(q)); tve = virt_ref(q, Td_, l.p); }
+        if (tie) { double q = T_; asm volatile("" : "+v"(q)); tve = virt_ref(q, Td_, l.p); }
         // A level exactly ON the LCL pairs the dry temperature with the saturation mixing ratio at the moist-adiabat
         // temperature (pf.py:773 uses <=).  For a saturated parcel this is the parcel's own level and the same holds.
         const bool on_lcl = need_w && !cross && (P == l.p);
-        if (__builtin_amdgcn_ballot_w64(on_lcl) != 0ull && on_lcl) {
+        if (on_lcl) {
             double ta = FAMILY ? l.t : m.at(P, X, a.tb);
             asm volatile("" : "+v"(ta));
             double ea = es_ref(ta);
@@ -538,7 +544,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // that they compare against 0 and 1 and the level count is not live in them (it used to be spilled and read back with
     // eight v_readlane per level).
     auto take = [&](bool more, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
-        P_ = np_; T2_ = nt_; M_ = ntd_;
+        // (one wait for the three values: left alone the compiler waits for each one just before its copy)
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_sched_barrier(0);
+        M_ = ntd_; T2_ = nt_; P_ = np_;                                    // (the value requested last first)
         if (more) load3(np_, nt_, ntd_);
         else { np_ = qnan(); nt_ = qnan(); ntd_ = qnan(); }
     };
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             }
         }
     } else {
+#ifdef XP_PB_WAITING_STAGE
         int rem = nlev - k;
         asm volatile("" : "+s"(rem));
         for (; rem >= 0; --rem, ++k) {
@@ -584,6 +593,23 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             if (TRACK) cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }
+#else
+        // Here the waiting stage of phase A (sP, sT, sM: level k - 1) is no longer needed -- every lane is one level behind
+        // the loads -- and carrying it cost three register moves per level.  The waiting level goes back into the
+        // look-ahead buffer (the request for level k that is in flight is dropped and made again: one row per tile, from
+        // L2), and from then on a level goes from the buffer straight into the node.
+        int rem = __builtin_amdgcn_readfirstlane(nlev - k);                // levels not yet requested into the buffer ...
+        if (rem > 0) { lp -= row_step; lt -= row_step; ld_ -= row_step; }
+        np_ = sP; nt_ = sT; ntd_ = sM;
+        rem += 1;                                                          // ... nodes still to feed: levels k - 1 ... nlev - 1
+        asm volatile("" : "+s"(rem));
+        for (; rem > 0; --rem, ++k) {
+            double P, T_, M_;
+            take(rem > 1, P, T_, M_);
+            if (TRACK) cur_k = k - 1;
+            moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+        }
+#endif
     }
     if (TRACK) {
         if (last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
