@@ -240,6 +240,22 @@ template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) 
 XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p, bool fast = false) {
     return EPS * fdiv(es_tab(tb, td, fast), p - es_tab(tb, t, fast));
 }
+// The environment's virtual temperature of a level, T (1 + 0.608 w(T, Td, p)) (pf.py:839-843), for the level loops: the two
+// constants as one, and the reciprocal with ONE Newton step on v_rcp_f64 (2.2e-15 relative, measured: scripts/dbg/rcp_err.hip;
+// in Tv that is 1e-14 K, a fraction of its last bit) -- five instructions less per level than virt(t, mixing_ratio_tab(...)).
+// Knife-edge nodes (saturated parcels) do not come through here: they take virt_ref, the reference's own operation order.
+XP_DEV double frcp1(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
+// (The dry parcel's virtual temperature is its temperature times the SAME factor at the parcel's own level: at that level
+// parcel and environment are the same air, and the two virtual temperatures have to come out bit-identical -- their
+// difference there decides "the parcel is never warmer than the environment", pf.py:1166-1169.)
+XP_DEV double virt_factor_tab(const double *tb, double t, double td, double p, bool fast) {
+    const double e_td = es_tab(tb, td, fast), e_t = es_tab(tb, t, fast);
+    return __builtin_fma(e_td * frcp1(p - e_t), VT_EPS * EPS, 1.0);
+}
+XP_DEV double virt_env_tab(const double *tb, double t, double td, double p, bool fast) { return t * virt_factor_tab(tb, t, td, p, fast); }
 // stage the table (global -> LDS); every thread of the block must call this before any early return
 XP_DEV const double *stage_es_table(const double *g, double *lds) {
     for (int i = threadIdx.x; i < LDS_TAB; i += blockDim.x) lds[i] = g[i];

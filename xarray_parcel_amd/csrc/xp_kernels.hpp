@@ -301,7 +301,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
     sti(s.parcel_idx, c, pc.idx);
     st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
-    const double w_parcel = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0; // pf.py:748
+    const double vf_parcel = need_w ? virt_factor_tab(es, pc.t, pc.td, pc.p, false) : 1.0;   // 1 + 0.608 w of the parcel (pf.py:748, 767)
     // ln p bookkeeping.  Levels use the table logarithm; the LCL node uses the library log (its crossing tests
     // "p* < p_lcl" then break ties as on the CPU); a level that sits exactly on the LCL pressure takes the LCL's
     // value so that the interval between the two stays zero-width; and the parcel's own ln p (x0) is whatever its
@@ -416,16 +416,16 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         if (!Q) dist = umax_(dist, table_dist(m_));
         if (PARCEL_ES && need_w) dist = umax_(dist, table_dist(tf));
         const bool in_range = all_in_table(dist) && (!FAM_T || in_table(tf, 8.0));
-        double ep = 0.0, we, tpf = 0.0;
+        double ep = 0.0, tve, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
-            we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, true);
+            tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, true);
             if (FAM_T) tpf = Family::temperature_from(es, P, tf, fam_off, true);
         } else {
             double tq = tf;
             asm volatile("" : "+v"(tq));
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
-            we = Q ? ((m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : mixing_ratio_tab(es, T_, m_, P, false);
+            tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, false);
             if (FAM_T) tpf = Family::temperature_from(es, P, tq, fam_off, false);
         }
         double tp, tvp;
@@ -436,7 +436,6 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             tp = tf;
             tvp = need_w ? virt(tp, mix_of_e(ep, P)) : tp;                                // pf.py:760
         }
-        double tve = need_w ? virt(T_, we) : T_;                                          // pf.py:839-843
         emit(std::true_type{}, P, X, tp, tvp, T_, tve, m_, false);
     };
     // Phase A: the wavefront's columns sit on both sides of their LCLs.  Every lane feeds exactly ONE node per iteration:
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         double tp, tvp;
         if (!skew) {                                                       // dry adiabat (pf.py:313, 767)
             tp = pc.t * fexp(KAPPA * (X - x0));
-            tvp = need_w ? virt(tp, w_parcel) : tp;
+            tvp = need_w ? tp * vf_parcel : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
             tvp = fam.at(X);
             tp = PROFILE ? Family::temperature_from(es, P, tvp, fam_off) : !vtc ? Family::temperature_of(es, P, tvp) : tvp;
@@ -489,8 +488,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         }
         double tve = T_;                                                   // pf.py:839-843, 911-920
         if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
-            if (__builtin_amdgcn_ballot_w64(!all_in_table(umax_(table_dist(T_), table_dist(Td_)))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
-            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
+            if (__builtin_amdgcn_ballot_w64(!all_in_table(umax_(table_dist(T_), table_dist(Td_)))) == 0ull) tve = virt_env_tab(es, T_, Td_, P, true);
+            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt_env_tab(es, tq, Td_, P, false); }
         }
         // For a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at the LCL node is rounding
         // noise of exactly the reference's expressions: those columns evaluate them in its operation order.
@@ -605,7 +604,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         asm volatile("" : "+s"(rem));
         for (; rem > 0; --rem, ++k) {
             double P, T_, M_;
-            take(rem > 1, P, T_, M_);
+            // (take() without its NaN refill: what the buffer holds after the last level is never looked at here; the value
+            // requested last is copied first, so that the compiler's one wait covers all three)
+            M_ = ntd_; T_ = nt_; P = np_;
+            if (rem > 1) load3(np_, nt_, ntd_);
             if (TRACK) cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
         }

@@ -47,7 +47,7 @@ struct Lev { double P, X, T, Td, tve; };      // one level with its environment 
 
 struct Chain {
     double lp, xl, lt;     // LCL pressure, its logarithm, LCL temperature
-    double pt, x0, wpar;   // dry adiabat below the LCL: parcel temperature, ln of its pressure, its mixing ratio (pf.py:748)
+    double pt, x0, vfac;   // dry adiabat below the LCL: parcel temperature, ln of its pressure, 1 + 0.608 x its mixing ratio (pf.py:748)
     int first;             // first level of the grid that belongs to this chain's profile (INT_MAX: blank chain)
     int status;
     bool done;             // the LCL node has been fed: the chain consumes `prev` from now on
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         if constexpr (NP > 2) f(h2, std::integral_constant<int, 2>{});
     };
     auto env_tv = [&](double T_, double Td_, double P) __attribute__((always_inline)) {          // pf.py:839-843 (rare paths: own range test)
-        return need_w ? virt(T_, mixing_ratio_tab(es, T_, Td_, P, false)) : T_;
+        return need_w ? virt_env_tab(es, T_, Td_, P, false) : T_;
     };
 
     // One node of chain h below / at / just above its LCL -- the logic of k_cape_cin's phase A (`source`), on one level
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         double tp, tvp;
         if (!skew) {                                                               // dry adiabat (pf.py:313, 767)
             tp = h.pt * fexp(KAPPA * (X - h.x0));
-            tvp = need_w ? virt(tp, h.wpar) : tp;
+            tvp = need_w ? tp * h.vfac : tp;
         } else {                                                                   // the table holds the virtual temperature
             tvp = h.fam.at(X);
             tp = !vtc ? Family::temperature_of(es, P, tvp) : tvp;
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         }
         double tve = T_;                                                           // pf.py:839-843, 911-920
         if (need_w) {                                                              // one wave-uniform range test for the two e_s
-            if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt(T_, mixing_ratio_tab(es, T_, Td_, P, true));
-            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt(tq, mixing_ratio_tab(es, tq, Td_, P, false)); }
+            if (__builtin_amdgcn_ballot_w64(!(in_table(T_, 0.0) && in_table(Td_, 0.0))) == 0ull) tve = virt_env_tab(es, T_, Td_, P, true);
+            else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt_env_tab(es, tq, Td_, P, false); }
         }
         const bool tie = need_w && cross && h.sat;
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull && tie) { double q = T_; asm volatile("" : "+v"(q)); tve = virt_ref(q, Td_, h.lp); }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         const ScalarsOut &s = a.s[i];
         double *const slot = s_slot + i * (SLOT_FIELDS * SLOT_STRIDE) + threadIdx.x;
         h.status = l.not_converged ? 2 : 0;
-        h.lp = l.p; h.lt = l.t; h.xl = qnan(); h.pt = pc.t; h.x0 = qnan(); h.wpar = 0.0;
+        h.lp = l.p; h.lt = l.t; h.xl = qnan(); h.pt = pc.t; h.x0 = qnan(); h.vfac = 1.0;
         h.sat = false; h.done = true; h.first = DEAD;
         h.li_p = h.li_e = h.li_q = qnan(); h.li_done = false;
         h.fam.tab = s_fam; h.fam.q = 0; h.fam.s = 0.0; h.fam.bad = false; h.fam.poison();
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
             st(s.lcl_p, s.f64, c, l.p); st(s.lcl_t, s.f64, c, l.t); st(s.lcl_tv, s.f64, c, l.tv);
             sti(s.parcel_idx, c, pc.idx);
             st(s.par_p, s.f64, c, pc.p); st(s.par_t, s.f64, c, pc.t); st(s.par_td, s.f64, c, pc.td);
-            h.wpar = need_w ? mixing_ratio_tab(es, pc.t, pc.td, pc.p) : 0.0;         // pf.py:748
+            h.vfac = need_w ? virt_factor_tab(es, pc.t, pc.td, pc.p, false) : 1.0; // pf.py:748
             // ln p bookkeeping as in k_cape_cin: library log for the LCL, table logarithm for levels, and the parcel's own
             // ln p is whatever its level gets (the surface parcel reproduces its level bit for bit, pf.py:1117-1120)
             h.xl = log(l.p);
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
             cur.X = log_tab<true>(es, cur.P);
             cur.tve = cur.T;
             if (need_w) {
-                if (__builtin_amdgcn_ballot_w64(!(in_table(cur.T, 0.0) && in_table(cur.Td, 0.0))) == 0ull) cur.tve = virt(cur.T, mixing_ratio_tab(es, cur.T, cur.Td, cur.P, true));
-                else { double tq = cur.T; asm volatile("" : "+v"(tq)); cur.tve = virt(tq, mixing_ratio_tab(es, tq, cur.Td, cur.P, false)); }
+                if (__builtin_amdgcn_ballot_w64(!(in_table(cur.T, 0.0) && in_table(cur.Td, 0.0))) == 0ull) cur.tve = virt_env_tab(es, cur.T, cur.Td, cur.P, true);
+                else { double tq = cur.T; asm volatile("" : "+v"(tq)); cur.tve = virt_env_tab(es, tq, cur.Td, cur.P, false); }
             }
             prev = cur;
         }
