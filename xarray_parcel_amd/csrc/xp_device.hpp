@@ -742,7 +742,8 @@ struct Scan {
     double cape, cin;
     // crossings, kept as ln p: pressures decrease along the scan, so "bottom LFC" / "top EL" order the same in ln p,
     // and the two exponentials a column actually needs are taken once, in finish()
-    bool any_inc, pos_parcel, env_any;
+    int any_inc;             // (an int, not a bool: set inside divergent code, a mask in scalar registers would have to be merged back at every join of every node)
+    bool pos_parcel, env_any;
     bool top_le, any_valid;  // at the last node where p, parcel, environment all exist: parcel <= environment; there is one
     bool bad_p;              // a pressure higher than the node before it (outside the input contract)
 
@@ -753,7 +754,8 @@ struct Scan {
         for (int f = 0; f < SLOT_FIELDS; ++f)
             slot[f * SLOT_STRIDE] = (f == SL_LFC_T || f == SL_EL_T || f == SL_LFC_X || f == SL_EL_X || f == SL_MIN_P || f == SL_LI) ? qnan() : 0.0;
         idx()[0] = -1; idx()[1] = -1;
-        any_inc = pos_parcel = env_any = top_le = any_valid = bad_p = false;
+        any_inc = 0;
+        pos_parcel = env_any = top_le = any_valid = bad_p = false;
     }
     XP_DEV int *idx() const { return (int *)(slot + SL_IDX * SLOT_STRIDE); }     // [0] lfc index, [1] el index
     XP_DEV void add(double a) {                      // skip-NaN sums (pf.py:206) with the sign filters of pf.py:201-204
@@ -789,13 +791,16 @@ struct Scan {
             // or Xp missing makes xs NaN, and then both triangles and the plain trapezoid are NaN too: nothing to add,
             // nothing to record.  (Twelve instructions less than the general form below on a path that some lane of a
             // wavefront takes at ~90 % of the levels of the bench's columns.)
-            const double r = frcp(d);
+            // (frcp1: 2.2e-15 relative, 1.5e-14 in the crossing's ln p.  The general form below uses the same reciprocal: whether a
+            // node is fed in phase A or in phase B depends on the OTHER columns of the wavefront, so the two forms have to agree
+            // to the last bit -- tests/test_gpu_parity.py::test_full_size_properties_config2, permutation equivariance)
+            const double r = frcp1(d);
             xs = (y * Xp - yp * X) * r;
             if (isnan_(xs)) return;
             frac = -yp * r;
             add((yp * 0.5) * fabs(Xp - xs));                                // lower triangle (pf.py:1246-1273)
             if (y > 0.0) {                                                  // increasing crossing
-                any_inc = true;
+                any_inc = 1;
                 if (!(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {                // bottom LFC (pf.py:1127-1132)
                     slot[SL_LFC_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[0] = j - 1;
                     if (!LEAN) slot[SL_LFC_T * SLOT_STRIDE] = frac * (par - parp) + parp;     // pf.py:1050
@@ -815,7 +820,7 @@ struct Scan {
             xs = (y * Xp - yp * X) / d;                                     // pf.py:1046
             frac = (xs - Xp) / (X - Xp);
         } else {
-            double r = frcp(d);
+            double r = frcp1(d);                                            // (the same reciprocal as the ABOVE form: see there)
             xs = (y * Xp - yp * X) * r;
             frac = -yp * r;                                                 // = (xs - Xp) / (X - Xp)
         }
@@ -837,7 +842,7 @@ struct Scan {
         if (!isnan_(xs)) {
             bool in_sel = ABOVE || use_all || i >= 1;
             if (y > 0.0 && in_sel) {                                        // increasing crossing
-                any_inc = true;
+                any_inc = 1;
                 if (above && !(xs <= slot[SL_LFC_X * SLOT_STRIDE])) {        // bottom LFC above the LCL (pf.py:1127-1132)
                     slot[SL_LFC_X * SLOT_STRIDE] = xs; if (!LEAN) idx()[0] = i;
                     if (!LEAN) slot[SL_LFC_T * SLOT_STRIDE] = ys;
@@ -883,7 +888,7 @@ struct Scan {
             bad_p = bad_p || (X > Xp);                                      // NaN compares false: a missing pressure is not "bad"
             env_any = env_any || !isnan_(env);
         }
-        bool pv = !isnan_(P);
+        bool pv = (ABOVE && LEAN) || !isnan_(P);                            // (ABOVE: a NaN pressure comes with a NaN parcel; the all-outputs kernels record P below)
         bool valid = pv && !isnan_(par) && !isnan_(env);                                    // p, parcel and environment all exist
         if (!LEAN && pv) slot[SL_MIN_P * SLOT_STRIDE] = P;                  // lowest valid pressure so far = the last one (LEAN: the kernel tracks the level index instead)
         top_le = (valid & (par <= env)) | (!valid & top_le);                      // (mask logic on the scalar unit: as a select the compiler round-trips the booleans through VGPRs)
@@ -905,7 +910,7 @@ struct Scan {
         if (!el_ok) { el_p = qnan(); el_t = qnan(); el_idx = -1; }
         if (!any_valid && env_any) r.status |= 1;                               // assert of pf.py:1149
         if (bad_p) r.status |= 8;                                               // XP_ST_BAD_PRESSURE
-        bool lfc_missing = !any_inc;
+        bool lfc_missing = any_inc == 0;
         bool replace = (pos_parcel && lfc_missing) ||
                        (!lfc_missing && isnan_(lfc_p) && (el_p < p_lcl));       // pf.py:1161-1180
         double L, cL, nL;
