@@ -873,7 +873,9 @@ struct Scan {
         asm volatile("" : "+v"(par), "+v"(env));
         double y = par - env;
         // same sign <=> y*yp > 0 or both zero; NaN (and the first node, yp = NaN) is "not same"
-        bool same = (y * yp > 0.0) || (y == 0.0 && yp == 0.0);
+        // (three comparisons and two mask operations, no branch: with the short-circuit form the compiler nested two exec-mask
+        // regions here, and some lane of a wavefront has y * yp <= 0 at most levels)
+        bool same = (y * yp > 0.0) | ((y == 0.0) & (yp == 0.0));
         double a = fabs(X - Xp) * ((yp + y) * 0.5);                         // pf.py:186-198
         add(same ? a : 0.0);
 #ifdef XP_NODE_BALLOT
