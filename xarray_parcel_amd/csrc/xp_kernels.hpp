@@ -232,14 +232,26 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
     // One LDS object with the e_s / ln table FIRST: at LDS address 0 the table base folds into the immediate offsets of the
     // ds_read instructions (the table is read ~15 times per level; behind the slots every access paid a v_mov for the base).
+    // (Not for the family kernels with profile output: they sit at the 128-VGPR cap, and with the one-object layout the
+    // register allocator spilled 18 instead of 12 VGPRs there -- c3 in family mode 27.2 -> 30.8 ms.  They keep separate arrays.)
     struct Lds { double es[LDS_TAB]; double fam[FAMILY ? FAM_SIZE : 1]; double slot[SLOT_FIELDS * SLOT_STRIDE]; int next; };
-    __shared__ Lds lds;
+    struct LdsRef { double *es, *fam, *slot; int *next; } lds;
+    if constexpr (FAMILY && PROFILE) {
+        __shared__ double l_es[LDS_TAB];
+        __shared__ double l_fam[FAM_SIZE];
+        __shared__ double l_slot[SLOT_FIELDS * SLOT_STRIDE];
+        __shared__ int l_next;
+        lds.es = l_es; lds.fam = l_fam; lds.slot = l_slot; lds.next = &l_next;
+    } else {
+        __shared__ Lds l;
+        lds.es = l.es; lds.fam = l.fam; lds.slot = l.slot; lds.next = &l.next;
+    }
     double *const s_es = lds.es;
     // family mode: the coefficient table lives in LDS too (46.7 KB; read 81 doubles at a time by lanes that differ only in
     // their psi-piece: broadcast + adjacent banks, conflict-free, ~100 cycles instead of an L2 round trip per batch)
     double *const s_fam = lds.fam;
     if (FAMILY) for (int i = threadIdx.x; i < FAM_SIZE; i += blockDim.x) s_fam[i] = a.fam_tab[i];
-    int &s_next = lds.next;                                                // PERSIST: the workgroup's next tile
+    int &s_next = *lds.next;                                               // PERSIST: the workgroup's next tile
     if (PERSIST && threadIdx.x == 0) s_next = (int)(blockDim.x >> 6);
     // PERSIST (family mode, large grids; the host decides): the grid is one workgroup per CU, the tables are staged once,
     // and every wavefront takes 64-column tiles from an atomic counter until the grid is done -- no staging and no drain
@@ -584,7 +596,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         }
     } else {
 #ifdef XP_PB_WAITING_STAGE
-        int rem = nlev - k;
+        int rem = __builtin_amdgcn_readfirstlane(nlev - k);
         asm volatile("" : "+s"(rem));
         for (; rem >= 0; --rem, ++k) {
             const double P = sP, T_ = sT, M_ = sM;
