@@ -13,6 +13,7 @@ struct OutView { void *data; int64_t ls, cs; };
 template <typename T> XP_DEV double ld(const View &v, int64_t k, int64_t c) {
     return (double)((const T *)v.data)[k * v.ls + c * v.cs];
 }
+template <typename T> XP_DEV T ldr(const View &v, int64_t k, int64_t c) { return ((const T *)v.data)[k * v.ls + c * v.cs]; }   // raw: no conversion at the load
 template <typename T> XP_DEV double ld1(const void *p, int64_t c) { return (double)((const T *)p)[c]; }
 XP_DEV void st(void *p, int f64, int64_t i, double v) {
     if (p == nullptr) return;
@@ -70,10 +71,12 @@ template <typename T, bool HUM> XP_DEV Parcel select_mu_exact(const CapeArgs &a,
     Parcel r; r.p = r.t = r.td = qnan(); r.first = a.nlev; r.idx = -1; r.prepend = false;
     double bottom = qnan(), bound = qnan(), dmin = qnan(), best = qnan();
     // one-level software prefetch: the loop is otherwise a chain of dependent HBM round trips
-    double np_ = ld<T>(a.p, 0, c), nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);
+    // (the look-ahead values stay in the INPUT type until they are used: converting an fp32 value at the load makes the
+    // wavefront wait for the load right there, and the prefetch hides nothing)
+    T np_ = ldr<T>(a.p, 0, c), nt_ = ldr<T>(a.t, 0, c), ntd_ = ldr<T>(a.td, 0, c);
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        double p = (double)np_, t = (double)nt_, td = as_dewpoint<HUM>(es, p, t, (double)ntd_);
+        if (k + 1 < a.nlev) { np_ = ldr<T>(a.p, k + 1, c); nt_ = ldr<T>(a.t, k + 1, c); ntd_ = ldr<T>(a.td, k + 1, c); }
         if (isnan_(p)) continue;
         if (isnan_(bottom)) { bottom = p; bound = bottom - depth; }
         double d = fabs(p - bound);
@@ -169,10 +172,10 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
     double pp = qnan(), thp = qnan(), wp = qnan();        // previous row of the layer
     double pb = qnan(), thb = qnan(), wb = qnan();        // last row with a valid pressure >= top
     bool closed = false;
-    double np_ = p_start, nt_ = ld<T>(a.t, 0, c), ntd_ = ld<T>(a.td, 0, c);      // one-level software prefetch
+    T np_ = ldr<T>(a.p, 0, c), nt_ = ldr<T>(a.t, 0, c), ntd_ = ldr<T>(a.td, 0, c);   // one-level software prefetch, in the input type (see select_mu_exact)
     for (int64_t k = 0; k < a.nlev; ++k) {
-        double p = np_, t = nt_, td = as_dewpoint<HUM>(es, np_, nt_, ntd_);
-        if (k + 1 < a.nlev) { np_ = ld<T>(a.p, k + 1, c); nt_ = ld<T>(a.t, k + 1, c); ntd_ = ld<T>(a.td, k + 1, c); }
+        double p = (double)np_, t = (double)nt_, td = as_dewpoint<HUM>(es, p, t, (double)ntd_);
+        if (k + 1 < a.nlev) { np_ = ldr<T>(a.p, k + 1, c); nt_ = ldr<T>(a.t, k + 1, c); ntd_ = ldr<T>(a.td, k + 1, c); }
         if (isnan_(bottom) && !isnan_(p)) { bottom = p; top = bottom - depth; }
         if (!isnan_(p) && p < top) {
             // insert the interpolated top row, close the integral; the profile continues from this level
@@ -536,14 +539,16 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // flat loads, which also count against the LDS counter and so make every LDS wait a memory wait)
     typedef const char __attribute__((address_space(1))) *GPtr;
     GPtr lp = nullptr, lt = nullptr, ld_ = nullptr;
-    double np_ = qnan(), nt_ = qnan(), ntd_ = qnan();
+    // (the look-ahead buffer holds the values as they are in memory: an fp32 level is converted when it is TAKEN -- converting
+    // at the load made every fp32 kernel wait for its loads on the spot, i.e. run without any prefetch)
+    T np_ = (T)qnan(), nt_ = (T)qnan(), ntd_ = (T)qnan();
     auto seek = [&](int64_t kk) __attribute__((always_inline)) {             // the next load3() reads level kk
         const int64_t o = kk * row_step + lane_off;
         lp = (GPtr)a.p.data + o; lt = (GPtr)a.t.data + o; ld_ = (GPtr)a.td.data + o;
     };
-    auto load3 = [&](double &P_, double &T2_, double &Td2_) __attribute__((always_inline)) {
+    auto load3 = [&](T &P_, T &T2_, T &Td2_) __attribute__((always_inline)) {
         typedef const T __attribute__((address_space(1))) *GT;
-        P_ = (double)*(GT)lp; T2_ = (double)*(GT)lt; Td2_ = (double)*(GT)ld_;
+        P_ = *(GT)lp; T2_ = *(GT)lt; Td2_ = *(GT)ld_;
         lp += row_step; lt += row_step; ld_ += row_step;
         asm volatile("" : "+v"(lp), "+v"(lt), "+v"(ld_));                  // (keeps the walk: no re-derivation from the level index)
     };
@@ -557,9 +562,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     auto take = [&](bool more, double &P_, double &T2_, double &M_) __attribute__((always_inline)) {
         // (one wait for the three values: left alone the compiler waits for each one just before its copy)
         __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_sched_barrier(0);
-        M_ = ntd_; T2_ = nt_; P_ = np_;                                    // (the value requested last first)
+        M_ = (double)ntd_; T2_ = (double)nt_; P_ = (double)np_;            // (the value requested last first)
         if (more) load3(np_, nt_, ntd_);
-        else { np_ = qnan(); nt_ = qnan(); ntd_ = qnan(); }
+        else { np_ = (T)qnan(); nt_ = (T)qnan(); ntd_ = (T)qnan(); }
     };
     constexpr bool Q = HUM && !PROFILE;
     for (; k <= nlev; ++k) {                                             // phase A (the searching parcels: per-lane level index)
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         int ku = nlev + 1;
         for (int probe = 0; probe <= nlev; ++probe) if (__ballot(resume <= probe) != 0ull) { ku = probe; break; }
         seek(ku);
-        np_ = qnan(); nt_ = qnan(); ntd_ = qnan();
+        np_ = (T)qnan(); nt_ = (T)qnan(); ntd_ = (T)qnan();
         if (ku < nlev) load3(np_, nt_, ntd_);
         int rem = nlev - ku;
         asm volatile("" : "+s"(rem));
@@ -611,14 +616,14 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // L2), and from then on a level goes from the buffer straight into the node.
         int rem = __builtin_amdgcn_readfirstlane(nlev - k);                // levels not yet requested into the buffer ...
         if (rem > 0) { lp -= row_step; lt -= row_step; ld_ -= row_step; }
-        np_ = sP; nt_ = sT; ntd_ = sM;
+        np_ = (T)sP; nt_ = (T)sT; ntd_ = (T)sM;                            // (levels: exact in T)
         rem += 1;                                                          // ... nodes still to feed: levels k - 1 ... nlev - 1
         asm volatile("" : "+s"(rem));
         for (; rem > 0; --rem, ++k) {
             double P, T_, M_;
             // (take() without its NaN refill: what the buffer holds after the last level is never looked at here; the value
             // requested last is copied first, so that the compiler's one wait covers all three)
-            M_ = ntd_; T_ = nt_; P = np_;
+            M_ = (double)ntd_; T_ = (double)nt_; P = (double)np_;
             if (rem > 1) load3(np_, nt_, ntd_);
             if (TRACK) cur_k = k - 1;
             moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
