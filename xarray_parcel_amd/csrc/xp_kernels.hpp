@@ -576,6 +576,26 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // (counting phase A down as well costs the surface / explicit-parcel kernels 60-70 spilled VGPRs at the 128 cap: measured)
     // Phase B: every lane is past its LCL and one level behind the loads: the level in (sP, sT, sM) is fed while the next
     // one arrives; the iteration past the top level feeds the last one.
+    // The plain walk: the waiting stage of phase A (sP, sT, sM: level k - 1) is no longer needed -- every lane is one level
+    // behind the loads -- and carrying it cost three register moves per level.  The waiting level goes back into the
+    // look-ahead buffer (the request for level k that is in flight is dropped and made again: one row per tile, from L2),
+    // and from then on a level goes from the buffer straight into the node.  Needs (sP, sT, sM) to be a LEVEL (exact in T).
+    auto plain_walk = [&](int k_) __attribute__((always_inline)) {
+        int rem = __builtin_amdgcn_readfirstlane(nlev - k_);               // levels not yet requested into the buffer ...
+        if (rem > 0) { lp -= row_step; lt -= row_step; ld_ -= row_step; }
+        np_ = (T)sP; nt_ = (T)sT; ntd_ = (T)sM;
+        rem += 1;                                                          // ... nodes still to feed: levels k - 1 ... nlev - 1
+        asm volatile("" : "+s"(rem));
+        for (; rem > 0; --rem, ++k_) {
+            double P, T_, M_;
+            // (take() without its NaN refill: what the buffer holds after the last level is never looked at here; the value
+            // requested last is copied first, so that the compiler's one wait covers all three)
+            M_ = (double)ntd_; T_ = (double)nt_; P = (double)np_;
+            if (rem > 1) load3(np_, nt_, ntd_);
+            if (TRACK) cur_k = k_ - 1;
+            moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
+        }
+    };
     if constexpr (SEARCH) {
         // ... with a WAVE-UNIFORM level index.  The columns of a searching parcel start at their own levels, so after
         // phase A the lanes stand on different levels and every load would touch as many level rows as there are distinct
@@ -590,6 +610,8 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         if (ku < nlev) load3(np_, nt_, ntd_);
         int rem = nlev - ku;
         asm volatile("" : "+s"(rem));
+        // (Leaving this gated loop for the plain walk once every lane has joined was measured: mixed-layer +- 0, most-unstable
+        // + 3.7 %, and the profile-output kernels spill over a hundred VGPRs with two copies of the node code.)
         for (; rem >= 0; --rem, ++ku) {
             double Pn, Tn, Mn;
             take(rem > 1, Pn, Tn, Mn);
@@ -600,35 +622,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             }
         }
     } else {
-#ifdef XP_PB_WAITING_STAGE
-        int rem = __builtin_amdgcn_readfirstlane(nlev - k);
-        asm volatile("" : "+s"(rem));
-        for (; rem >= 0; --rem, ++k) {
-            const double P = sP, T_ = sT, M_ = sM;
-            take(rem > 1, sP, sT, sM);
-            if (TRACK) cur_k = k - 1;
-            moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
-        }
-#else
-        // Here the waiting stage of phase A (sP, sT, sM: level k - 1) is no longer needed -- every lane is one level behind
-        // the loads -- and carrying it cost three register moves per level.  The waiting level goes back into the
-        // look-ahead buffer (the request for level k that is in flight is dropped and made again: one row per tile, from
-        // L2), and from then on a level goes from the buffer straight into the node.
-        int rem = __builtin_amdgcn_readfirstlane(nlev - k);                // levels not yet requested into the buffer ...
-        if (rem > 0) { lp -= row_step; lt -= row_step; ld_ -= row_step; }
-        np_ = (T)sP; nt_ = (T)sT; ntd_ = (T)sM;                            // (levels: exact in T)
-        rem += 1;                                                          // ... nodes still to feed: levels k - 1 ... nlev - 1
-        asm volatile("" : "+s"(rem));
-        for (; rem > 0; --rem, ++k) {
-            double P, T_, M_;
-            // (take() without its NaN refill: what the buffer holds after the last level is never looked at here; the value
-            // requested last is copied first, so that the compiler's one wait covers all three)
-            M_ = (double)ntd_; T_ = (double)nt_; P = (double)np_;
-            if (rem > 1) load3(np_, nt_, ntd_);
-            if (TRACK) cur_k = k - 1;
-            moist_node(P, log_tab<true>(es, P), T_, Q ? M_ : as_dewpoint<HUM>(es, P, T_, M_), Q);
-        }
-#endif
+        plain_walk(k);
     }
     if (TRACK) {
         if (last_k >= 0) sc.slot[SL_MIN_P * SLOT_STRIDE] = ld<T>(a.p, last_k, c);
