@@ -633,6 +633,13 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // missing).  (The mixed-layer parcel's own node lies at or below its LCL, so it never is the minimum.)
         double pm = l.p;
         bool found = false;
+        if constexpr (!SEARCH) {
+            // after the plain walk the look-ahead buffer still holds the top level (the last one taken; nothing was requested
+            // behind it): when its pressure is valid -- the normal case -- that is the answer, without a load whose round
+            // trip nothing would cover at this point
+            const double q = (double)np_;
+            if (!isnan_(q)) { pm = (q < pm) ? q : pm; found = true; }
+        }
         for (int kk = nlev - 1; kk >= (int)pc.first; --kk) {
             if (__ballot(!found) == 0ull) break;
             const double q = ld<T>(a.p, kk, c);
