@@ -237,6 +237,28 @@ template <bool SHORT = false> XP_DEV double log_tab(const double *tb, double x) 
     q = __builtin_fma(q, r, 1.0);
     return __builtin_fma((double)e, 0.6931471805599453, __builtin_fma(q, r, lc));
 }
+// exp(u) for the dry adiabat of the level loops, T0 (p / p0)^kappa = T0 exp(kappa (ln p - ln p0)): |u| is a few tenths at most,
+// so u = i / 64 + r with exp(i / 64) from 64 spare entries of the table block (row 2, i = -40 ... 23: u in [-0.63, 0.37]) and
+// exp(r), |r| <= 1/128, by its series through r^5 (3e-16) -- ~20 instructions instead of the ~45 of fexp (two scalar moves per
+// coefficient of its degree-12 polynomial).  u = 0 gives exactly 1 (the parcel's own level must reproduce its temperature bit
+// for bit, pf.py:1117-1120).  A lane outside the range takes the library exp.
+constexpr int EXPT_OFF = 2 * ES_STRIDE + ES_N, EXPT_LO = -40, EXPT_N = 64;
+XP_DEV double dry_factor(const double *tb, double u) {
+    const double k = __builtin_rint(u * 64.0);
+    const bool ok = (k >= (double)EXPT_LO) && (k <= (double)(EXPT_LO + EXPT_N - 1));        // NaN: not ok
+    const int i = ok ? (int)k - EXPT_LO : 0;
+    const double e = tb[EXPT_OFF + i];
+    const double r = __builtin_fma(k, -1.0 / 64.0, u);
+    lds_wait_all();
+    double q = fma_sc(1.0 / 120.0, r, 1.0 / 24.0);
+    q = fma_sc(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    q = __builtin_fma(q, r, 1.0);
+    double v = e * q;
+    if (!ok) { double w = u; asm volatile("" : "+v"(w)); v = exp_slow(w); }                  // (per lane, rare, out of line)
+    return v;
+}
 XP_DEV double mixing_ratio_tab(const double *tb, double t, double td, double p, bool fast = false) {
     return EPS * fdiv(es_tab(tb, td, fast), p - es_tab(tb, t, fast));
 }

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // only the parcel temperature / mixing ratio is branched, the environment and the scan node are shared
         double tp, tvp;
         if (!skew) {                                                       // dry adiabat (pf.py:313, 767)
-            tp = pc.t * fexp(KAPPA * (X - x0));
+            tp = pc.t * dry_factor(es, KAPPA * (X - x0));
             tvp = need_w ? tp * vf_parcel : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
             tvp = fam.at(X);

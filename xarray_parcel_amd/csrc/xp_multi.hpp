@@ -100,7 +100,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS) void k_cape_cin_multi(MultiArgs a)
         if (isnan_(P) && !skew && !last) h.status |= 4;                            // NaN pressure below the LCL (see xparcel.h)
         double tp, tvp;
         if (!skew) {                                                               // dry adiabat (pf.py:313, 767)
-            tp = h.pt * fexp(KAPPA * (X - h.x0));
+            tp = h.pt * dry_factor(es, KAPPA * (X - h.x0));
             tvp = need_w ? tp * h.vfac : tp;
         } else {                                                                   // the table holds the virtual temperature
             tvp = h.fam.at(X);

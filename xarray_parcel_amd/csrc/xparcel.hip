@@ -81,6 +81,8 @@ void build_es_table(double *out) {
         lt[i] = (double)(1.0L / c);
         lt[xp::ES_STRIDE + i] = (double)logl(c);
     }
+    // exp(i / 64) for xp::dry_factor: spare columns of row 2 (exp(0) = 1 exactly)
+    for (int i = 0; i < xp::EXPT_N; ++i) out[xp::EXPT_OFF + i] = (double)expl((LD)(i + xp::EXPT_LO) / 64.0L);
 }
 
 // Stages host buffers through device scratch for one call; device buffers pass through.
