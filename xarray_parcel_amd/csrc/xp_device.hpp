@@ -273,11 +273,34 @@ XP_DEV double frcp1(double x) {
 // (The dry parcel's virtual temperature is its temperature times the SAME factor at the parcel's own level: at that level
 // parcel and environment are the same air, and the two virtual temperatures have to come out bit-identical -- their
 // difference there decides "the parcel is never warmer than the environment", pf.py:1166-1169.)
-XP_DEV double virt_factor_tab(const double *tb, double t, double td, double p, bool fast) {
-    const double e_td = es_tab(tb, td, fast), e_t = es_tab(tb, t, fast);
+// e_s at two temperatures at once, both promised to lie inside the table: the twelve coefficients are requested together,
+// ONE wait, and the two Horner chains run interleaved (a dependent fp64 chain issues one instruction per ~8 cycles; two
+// independent ones fill each other's gaps).  Same values as two es_tab calls, bit for bit.
+XP_DEV void es_tab2(const double *tb, double t1, double t2, double &e1, double &e2) {
+    const double u1 = t1 - ES_T_LO, u2 = t2 - ES_T_LO;
+    const double *c1 = tb + (int)u1, *c2 = tb + (int)u2;
+    const double r1 = __builtin_amdgcn_fract(u1), r2 = __builtin_amdgcn_fract(u2);
+    static_assert(ES_DEG == 5, "es_tab2 is written out for degree 5");
+    double a0 = c1[0], a1 = c1[1 * ES_STRIDE], a2 = c1[2 * ES_STRIDE], a3 = c1[3 * ES_STRIDE], a4 = c1[4 * ES_STRIDE], a5 = c1[5 * ES_STRIDE];
+    double b0 = c2[0], b1 = c2[1 * ES_STRIDE], b2 = c2[2 * ES_STRIDE], b3 = c2[3 * ES_STRIDE], b4 = c2[4 * ES_STRIDE], b5 = c2[5 * ES_STRIDE];
+    lds_wait_all();
+    double p = __builtin_fma(a5, r1, a4), q = __builtin_fma(b5, r2, b4);
+    p = __builtin_fma(p, r1, a3); q = __builtin_fma(q, r2, b3);
+    p = __builtin_fma(p, r1, a2); q = __builtin_fma(q, r2, b2);
+    p = __builtin_fma(p, r1, a1); q = __builtin_fma(q, r2, b1);
+    e1 = __builtin_fma(p, r1, a0); e2 = __builtin_fma(q, r2, b0);
+}
+// PAIR: take es_tab2 on the promised-in-range path (twelve more VGPRs for a moment: the CAPE/CIN-only kernels have them, the
+// all-outputs kernels of the searching parcels would spill)
+template <bool PAIR = false> XP_DEV double virt_factor_tab(const double *tb, double t, double td, double p, bool fast) {
+    double e_td, e_t;
+    if (PAIR && fast) es_tab2(tb, td, t, e_td, e_t);
+    else { e_td = es_tab(tb, td, fast); e_t = es_tab(tb, t, fast); }
     return __builtin_fma(e_td * frcp1(p - e_t), VT_EPS * EPS, 1.0);
 }
-XP_DEV double virt_env_tab(const double *tb, double t, double td, double p, bool fast) { return t * virt_factor_tab(tb, t, td, p, fast); }
+template <bool PAIR = false> XP_DEV double virt_env_tab(const double *tb, double t, double td, double p, bool fast) {
+    return t * virt_factor_tab<PAIR>(tb, t, td, p, fast);
+}
 // stage the table (global -> LDS); every thread of the block must call this before any early return
 XP_DEV const double *stage_es_table(const double *g, double *lds) {
     for (int i = threadIdx.x; i < LDS_TAB; i += blockDim.x) lds[i] = g[i];

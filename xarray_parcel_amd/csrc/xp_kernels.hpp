@@ -434,7 +434,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         double ep = 0.0, tve, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
-            tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, true);
+            tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab<LEAN && !PROFILE>(es, T_, m_, P, true);
             if (FAM_T) tpf = Family::temperature_from(es, P, tf, fam_off, true);
         } else {
             double tq = tf;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         }
         double tve = T_;                                                   // pf.py:839-843, 911-920
         if (need_w) {                                                      // one wave-uniform range test for the two e_s, as in phase B
-            if (__builtin_amdgcn_ballot_w64(!all_in_table(umax_(table_dist(T_), table_dist(Td_)))) == 0ull) tve = virt_env_tab(es, T_, Td_, P, true);
+            if (__builtin_amdgcn_ballot_w64(!all_in_table(umax_(table_dist(T_), table_dist(Td_)))) == 0ull) tve = virt_env_tab<LEAN && !PROFILE>(es, T_, Td_, P, true);
             else { double tq = T_; asm volatile("" : "+v"(tq)); tve = virt_env_tab(es, tq, Td_, P, false); }
         }
         // For a saturated parcel (LCL == parcel level) the sign of parcel-minus-environment at the LCL node is rounding
