@@ -290,6 +290,28 @@ XP_DEV void es_tab2(const double *tb, double t1, double t2, double &e1, double &
     p = __builtin_fma(p, r1, a1); q = __builtin_fma(q, r2, b1);
     e1 = __builtin_fma(p, r1, a0); e2 = __builtin_fma(q, r2, b0);
 }
+// ... and with a third independent chain: the Horner evaluation of the adiabat-family polynomial (c[8] ... c[0] at z)
+XP_DEV void es_tab2_horner(const double *tb, double t1, double t2, const double *c, double z, double &e1, double &e2, double &h) {
+    const double u1 = t1 - ES_T_LO, u2 = t2 - ES_T_LO;
+    const double *c1 = tb + (int)u1, *c2 = tb + (int)u2;
+    const double r1 = __builtin_amdgcn_fract(u1), r2 = __builtin_amdgcn_fract(u2);
+    double a0 = c1[0], a1 = c1[1 * ES_STRIDE], a2 = c1[2 * ES_STRIDE], a3 = c1[3 * ES_STRIDE], a4 = c1[4 * ES_STRIDE], a5 = c1[5 * ES_STRIDE];
+    double b0 = c2[0], b1 = c2[1 * ES_STRIDE], b2 = c2[2 * ES_STRIDE], b3 = c2[3 * ES_STRIDE], b4 = c2[4 * ES_STRIDE], b5 = c2[5 * ES_STRIDE];
+    double v = __builtin_fma(c[8], z, c[7]);                                // (three steps of the long chain while the reads are in flight)
+    v = __builtin_fma(v, z, c[6]);
+    v = __builtin_fma(v, z, c[5]);
+    lds_wait_all();
+    double p = __builtin_fma(a5, r1, a4), q = __builtin_fma(b5, r2, b4);
+    v = __builtin_fma(v, z, c[4]);
+    p = __builtin_fma(p, r1, a3); q = __builtin_fma(q, r2, b3);
+    v = __builtin_fma(v, z, c[3]);
+    p = __builtin_fma(p, r1, a2); q = __builtin_fma(q, r2, b2);
+    v = __builtin_fma(v, z, c[2]);
+    p = __builtin_fma(p, r1, a1); q = __builtin_fma(q, r2, b1);
+    v = __builtin_fma(v, z, c[1]);
+    e1 = __builtin_fma(p, r1, a0); e2 = __builtin_fma(q, r2, b0);
+    h = __builtin_fma(v, z, c[0]);
+}
 // PAIR: take es_tab2 on the promised-in-range path (twelve more VGPRs for a moment: the CAPE/CIN-only kernels have them, the
 // all-outputs kernels of the searching parcels would spill)
 template <bool PAIR = false> XP_DEV double virt_factor_tab(const double *tb, double t, double td, double p, bool fast) {
@@ -719,6 +741,32 @@ struct Family {
     // VIRTUAL temperature of the column's parcel at ln p = X (X <= x_lcl; levels normally come with decreasing X).
     // x-piece j holds z in (-1, 1]: the fast path only tests that (the piece index itself is recovered from m4 when a
     // lane has to move, with the oracle's floor rule).
+    // at() in two steps, for a caller that has other arithmetic to interleave with the Horner chain (eight dependent fp64 fma):
+    // locate() makes sure the coefficients of X's piece are loaded and returns the piece-local coordinate; value() evaluates.
+    // any_top (wave-uniform): some lane is above the table top -- only then value() looks at the per-lane `top`.
+    XP_DEV double locate(double X, bool &top, bool &any_top) {
+        double z = __builtin_fma(2.0 / FAM_WX, X, m4);
+        top = false; any_top = false;
+        bool move = (z <= -1.0) || (z > 1.0);
+        if (__builtin_amdgcn_ballot_w64(move) != 0ull) {
+            double u = __builtin_fma(-(1.0 / FAM_WX), X, FAM_XHI * (1.0 / FAM_WX));
+            bool go = move;
+            if (go && u < 0.0) { bad = true; go = false; }
+            int jn = (int)u;
+            top = go && jn > FAM_NPX - 1;
+            int jcur = (int)__builtin_rint(__builtin_fma(m4, 0.5, FAM_XHI * (1.0 / FAM_WX) - 0.5));
+            int j = go ? (jn > FAM_NPX - 1 ? FAM_NPX - 1 : jn) : jcur;
+            load_piece(bad ? 0 : j);
+            if (bad) poison();
+            z = __builtin_fma(2.0 / FAM_WX, X, m4);
+            any_top = __builtin_amdgcn_ballot_w64(top) != 0ull;
+        }
+        return z;
+    }
+    XP_DEV double top_value(double v, double X, bool top) const {           // (rare: the dry continuation above the table top)
+        const double w = horner(-1.0);
+        return top ? w * fexp(KAPPA * (X - FAM_XLO)) : v;
+    }
     XP_DEV double at(double X) {
         double z = __builtin_fma(2.0 / FAM_WX, X, m4);
         // a NaN z stays put: a NaN pressure, or a column outside the table (poisoned below: its nine coefficients and m4

@@ -420,7 +420,13 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     auto moist_node = [&](double P, double X, double T_, double m_, bool Q) __attribute__((always_inline)) {
         // family mode: the table holds the parcel's VIRTUAL temperature; the plain temperature is derived from it only
         // where somebody wants it (profile output, no virtual-temperature correction)
-        const double tf = FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);     // NaN pressure -> NaN
+        // (family CAPE/CIN-only kernels: the Horner chain of the parcel's virtual temperature is evaluated together with the two
+        // e_s chains of the environment, below: three independent chains interleaved)
+        // (surface / explicit parcels: c2 -2.2 % same-box; the searching parcels' kernels, at 127-128 VGPRs, gain nothing)
+        constexpr bool TRIO = FAMILY && LEAN && !PROFILE && !HUM && (PMODE == PM_SURFACE || PMODE == PM_EXPLICIT);
+        bool f_top = false, f_any_top = false;
+        const double fz = TRIO ? fam.locate(X, f_top, f_any_top) : 0.0;
+        double tf = TRIO ? 0.0 : FAMILY ? fam.at(X) : m.at(P, X, a.tb, true);     // NaN pressure -> NaN
         // one wave-uniform range test per level instead of one per e_s evaluation; the two sides are separate code (the
         // asm barrier keeps the compiler from merging them into one path full of selects)
         constexpr bool PARCEL_ES = TABLE;                                  // exact mode: e_s(T) rides along with the RK4 state
@@ -434,15 +440,23 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         double ep = 0.0, tve, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
+            if constexpr (TRIO) {                                          // (LEAN implies the default options: need_w)
+                double e_td, e_t;
+                es_tab2_horner(es, m_, T_, fam.c, fz, e_td, e_t, tf);
+                tve = T_ * __builtin_fma(e_td * frcp1(P - e_t), VT_EPS * EPS, 1.0);        // = virt_env_tab, bit for bit
+            } else {
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab<LEAN && !PROFILE>(es, T_, m_, P, true);
+            }
             if (FAM_T) tpf = Family::temperature_from(es, P, tf, fam_off, true);
         } else {
+            if constexpr (TRIO) tf = fam.horner(fz);
             double tq = tf;
             asm volatile("" : "+v"(tq));
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, false);
             if (FAM_T) tpf = Family::temperature_from(es, P, tq, fam_off, false);
         }
+        if constexpr (TRIO) { if (f_any_top) tf = fam.top_value(tf, X, f_top); }
         double tp, tvp;
         if (FAMILY) {
             tvp = tf;
