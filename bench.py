@@ -275,6 +275,9 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-table-leg', action='store_true', help='skip the table-mode leg of the c2 / one-GPU run')
     ap.add_argument('--no-config-legs', action='store_true', help='skip the c3 / c4_share / c5_share / numpy / strong_c4 legs')
+    ap.add_argument('--preroll-seconds', type=float, default=0.5,
+                    help='untimed run of the same step before the W warmup + K timed steps, so that they see steady-state clocks '
+                         '(0: measure from an idle GPU; the first W + K steps are reported as cold_start either way)')
     ap.add_argument('--leg-scale', type=int, default=1, help='divide the column counts of the config legs by this (rehearsals, tests)')
     ap.add_argument('--dtype', default=None, choices=['f64', 'f32'])
     ap.add_argument('--moist', default='family', choices=['exact', 'family', 'table'],
@@ -436,6 +439,23 @@ def main():
         return leg
 
     h = run_cfg(cfg, a.moist, a.steps, a.warmup)
+    # Steady state.  A run that starts on an idle GPU measures its clock ramp: on MI355X the first ~10 ms of this kernel run
+    # ~7 % slower than the same kernel half a second later (and ~15 % slower than the boost the card reaches in between:
+    # DESIGN.md 7 "Clocks").  The driver's command line (--steps 20 --warmup 5) is 14 ms of GPU time in all.  So: the W + K
+    # steps just measured are reported as `cold_start`, then the same step runs untimed for --preroll-seconds, and W untimed
+    # + exactly K timed steps are taken again for `value`.  (Same number of extra steps on every rank: derived from the
+    # all-reduced cold time.)
+    cold = None
+    if a.preroll_seconds > 0:
+        ck = h['kernel_ms']
+        cold = {'ms_per_step': h['dt'] / a.steps * 1e3,
+                'kernel_ms_by_parcel': {pc: sum(e0.elapsed_time(e1) for e0, e1 in v) / len(v) for pc, v in ck.items()}}
+        n_pre = max(1, int(a.preroll_seconds / max(h['dt'] / a.steps, 1e-6)))
+        h['timed_steps'](a.moist, 0, n_pre, None)
+        k2 = {pc: [] for pc in h['parcels']}
+        dt2, last2 = h['timed_steps'](a.moist, a.steps, a.warmup, k2)
+        h['dt'], h['last'], h['kernel_ms'] = dt2, last2, k2
+        cold['preroll_steps'] = n_pre
     dt, last, kernel_ms, ncol, total_rows = h['dt'], h['last'], h['kernel_ms'], h['ncol'], h['total_rows']
     nlev, nx, parcels = h['nlev'], h['nx'], h['parcels']
 
@@ -484,6 +504,12 @@ def main():
                          'kernel_ms_by_parcel': per_parcel},
             'check': head_keep if strong is not None else {pc: {'max_cape': float(last[pc]['cape'].max()), 'min_cin': float(last[pc]['cin'].min())} for pc in parcels},
         }
+        if cold is not None:
+            ck = cold['kernel_ms_by_parcel'][dom]
+            out['cold_start'] = {'what': f"the first {a.warmup} + {a.steps} steps of this process, from an idle GPU (clock ramp), before the "
+                                         f"{cold['preroll_steps']} untimed steps (~{a.preroll_seconds} s) that precede the steps `value` is taken from",
+                                 'ms_per_step': cold['ms_per_step'], 'value': total_cols / (cold['ms_per_step'] * 1e-3), 'kernel_ms': ck,
+                                 'frac': bytes_launch / (ck * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if strong is not None:
             out['strong_c4'] = strong
         if a.config == 'c2' and world == 1 and not a.no_table_leg and a.humidity == 'dewpoint':

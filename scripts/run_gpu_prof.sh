@@ -8,7 +8,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o cu
 db=$(ls gpurun_out/prof_$tag/*/*.db gpurun_out/prof_$tag/*.db 2>/dev/null | head -1)
 python3 profiles/summarize.py "$db" gpurun_out/${tag}_stats.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-table-leg --no-config-legs $*" > /dev/null
 head -5 gpurun_out/${tag}_stats.txt
-timeout -k 10 400 rocprofv3 -i profiles/pmc_counters.txt --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-table-leg --no-config-legs "$@" > gpurun_out/${tag}_pmc.log 2>&1; echo pmc rc=$?
+timeout -k 10 400 rocprofv3 -i profiles/pmc_counters.txt --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --preroll-seconds 0 --no-cpu --no-table-leg --no-config-legs "$@" > gpurun_out/${tag}_pmc.log 2>&1; echo pmc rc=$?
 python3 - "$tag" "$@" <<'PY'
 import csv, glob, collections, json, sys
 sys.path.insert(0, '.')
@@ -22,7 +22,7 @@ for f in glob.glob(f'gpurun_out/pmc_{tag}/pmc_*/*/*_counter_collection.csv'):
         if r['Kernel_Name'].replace('void ', '').startswith(kernel):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 mean = {k: sum(v) / len(v) for k, v in sorted(agg.items())}
-out = {'command': 'rocprofv3 -i profiles/pmc_counters.txt --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-table-leg --no-config-legs ' + ' '.join(args),
+out = {'command': 'rocprofv3 -i profiles/pmc_counters.txt --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --preroll-seconds 0 --no-cpu --no-table-leg --no-config-legs ' + ' '.join(args),
        'kernel': kernel, 'shape': [bench['config']['levels'], bench['config']['columns_this_rank']], 'csrc_sha': _lib.csrc_sha(),
        'per_launch_mean': mean,
        'hbm_read_bytes_corrected': mean.get('FETCH_SIZE', 0) * 1024 * 2, 'hbm_write_bytes': mean.get('WRITE_SIZE', 0) * 1024,

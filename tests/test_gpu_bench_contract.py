@@ -30,6 +30,9 @@ def test_bench_json_contract():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
     assert d['value'] > 1e6
+    # the steps `value` comes from follow a steady-state pre-roll; the W + K steps from the idle GPU are reported beside them
+    cs = d['cold_start']
+    assert cs['kernel_ms'] > 0 and cs['ms_per_step'] > 0 and 0 < cs['frac'] < 1 and cs['value'] > 1e6
     # the other BASELINE configs as legs on the driver's clock (reduced by --leg-scale here), each with its oracle check
     for k in ('c3', 'c4_share', 'c5_share'):
         assert k in d and 'error' not in d[k], (k, d.get(k))
