@@ -600,7 +600,9 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         // (the dropped request is waited for HERE, once: left pending on phase A's buffer registers it made the compiler put
         // `s_waitcnt vmcnt` in front of the first reuse of those registers inside the loop -- in the middle of every iteration,
         // where it waited for the loads of THIS level's successor: half the prefetch distance gone)
+#ifndef XP_NO_PREWAIT
         __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_sched_barrier(0);
+#endif
         np_ = (T)sP; nt_ = (T)sT; ntd_ = (T)sM;
         rem += 1;                                                          // ... nodes still to feed: levels k - 1 ... nlev - 1
         asm volatile("" : "+s"(rem));
