@@ -506,6 +506,7 @@ def main():
         }
         if cold is not None:
             ck = cold['kernel_ms_by_parcel'][dom]
+            out['preroll'] = {'seconds': a.preroll_seconds, 'untimed_steps': cold['preroll_steps'], 'before': 'the W untimed + K timed steps of `value`', 'after': 'the W + K steps of `cold_start`'}
             out['cold_start'] = {'what': f"the first {a.warmup} + {a.steps} steps of this process, from an idle GPU (clock ramp), before the "
                                          f"{cold['preroll_steps']} untimed steps (~{a.preroll_seconds} s) that precede the steps `value` is taken from",
                                  'ms_per_step': cold['ms_per_step'], 'value': total_cols / (cold['ms_per_step'] * 1e-3), 'kernel_ms': ck,
