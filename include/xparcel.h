@@ -159,7 +159,9 @@ typedef struct {
     /* lifted_index (pf.py:1722): environment minus parcel temperature of THIS profile at `lifted_index_pressure` hPa
        (the reference: 500), by the log_interp rule of pf.py:1813 applied to the profile's rows -- ncol values of the
        profile's dtype / mem, written in the same pass; NULL = not wanted.  With all six arrays NULL the pass costs
-       little more than CAPE / CIN alone. */
+       little more than CAPE / CIN alone -- in family mode, with the default options and a CAPE/CIN-only xp_scalars_out
+       (see there), 10 % more: the parcel's plain temperature is then derived from the table's virtual temperature only at
+       the two nodes around the level (any other request in family mode derives it at every node: + 65 %). */
     void *lifted_index;
     double lifted_index_pressure;
 } xp_profile_out;

@@ -234,6 +234,50 @@ def test_lifted_index_in_the_same_pass(moist):
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.max(np.abs(got[ok] - ref[ok])) <= 1e-9
 
 
+def test_lifted_index_only_kernels_of_family_mode():
+    """Family mode, CAPE / CIN + the lifted index and nothing else (what the product bundle's parcel passes ask for): the
+    instantiation that inverts the parcel's virtual temperature only at the two nodes around the level, against the
+    profile-output kernel (every node inverted) and the composition on its written profile -- every parcel kind, fp64 and
+    fp32, NaN levels, the level on a grid level, grids that stop below it, and a grid large enough for persistent wavefronts."""
+    def check(p, t, td, tol, **kw):
+        full = xa.cape_cin_columns(p, t, td, moist='family', want_profile=True, **kw)
+        eager = xa.cape_cin_columns(p, t, td, moist='family', lifted_index_at=500.0, **kw)          # all scalars wanted: profile kernel
+        lazy = xa.cape_cin_columns(p, t, td, moist='family', lifted_index_at=500.0, want=('cape', 'cin'), **kw)
+        assert set(lazy) == {'cape', 'cin', 'lifted_index'}
+        ref = xa.lifted_index(full['profile'])
+        for k in ('cape', 'cin'):
+            assert np.array_equal(lazy[k], full[k], equal_nan=True), (kw, k)
+        assert np.array_equal(np.isnan(lazy['lifted_index']), np.isnan(ref)), kw
+        ok = ~np.isnan(ref)
+        assert np.max(np.abs(lazy['lifted_index'][ok] - ref[ok])) <= tol, (kw, np.max(np.abs(lazy['lifted_index'][ok] - ref[ok])))
+        assert np.max(np.abs(lazy['lifted_index'][ok] - eager['lifted_index'][ok])) <= tol
+        return int(ok.sum())
+    p, t, td = synth.columns(nlev=40, ncol=3000, seed=17, nan_fraction=0.08, dtype=np.float64)
+    for kw in ({}, {'parcel': 'mixed_layer', 'depth': 100}, {'parcel': 'mixed_layer', 'depth': 50}, {'parcel': 'most_unstable', 'depth': 250},
+               {'parcel': 'explicit', 'parcel_values': (p[0] + 5.0, t[0] + 1.0, td[0] - 1.0)}):
+        assert check(p, t, td, 1e-9, **kw) > 2000
+        assert check(*(v.astype(np.float32) for v in (p, t, td)), 2e-4, **{k: (tuple(x.astype(np.float32) for x in v) if k == 'parcel_values' else v)
+                                                                               for k, v in kw.items()}) > 2000
+    p2 = p.copy(); k500 = np.argmin(np.abs(p2 - 500.0), axis=0); p2[k500, np.arange(p2.shape[1])] = 500.0     # the level ON a grid level
+    assert check(p2, t, td, 1e-9) > 2000
+    low = [np.ascontiguousarray(v[:12]) for v in (p, t, td)]                                                  # grids that stop below it
+    assert np.all(np.isnan(xa.cape_cin_columns(*low, moist='family', lifted_index_at=500.0, want=('cape', 'cin'))['lifted_index']))
+    pb, tb, tdb = synth.columns(nlev=33, ncol=(3 << 18) + 77, seed=23, nan_fraction=0.05, dtype=np.float32)   # persistent wavefronts
+    for kw in ({}, {'parcel': 'most_unstable', 'depth': 300}):
+        assert check(pb, tb, tdb, 2e-4, **kw) > 500000
+    # against the NumPy oracle (RK4 adiabat: the family table is within 1e-6 K of it)
+    from oracle import parcel_oracle as po
+    got = xa.cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, moist='family', lifted_index_at=500.0, want=('cape', 'cin'))['lifted_index']
+    po.set_moist_lapse('rk4')
+    try:
+        for c in range(0, 3000, 97):
+            with np.errstate(all='ignore'):
+                _, mprof, _ = po.mixed_layer_cape_cin(p[:, c], t[:, c], td[:, c], depth=100)
+                want = po.lifted_index(mprof)
+            assert (np.isnan(want) and np.isnan(got[c])) or abs(want - got[c]) <= 1e-5, (c, want, got[c])
+    finally:
+        po.set_moist_lapse('ode')
+
 @pytest.mark.parametrize('moist', ['exact', 'family'])
 def test_explicit_parcel_and_ragged_shapes(moist):
     # ncol not a multiple of the wavefront / block (1024 columns per workgroup in family mode), 1 column, 1 level

@@ -34,7 +34,19 @@ template <typename T, int PM, int MODE, bool PERSIST> void launch_p(const CapeAr
         else hipLaunchKernelGGL((k_cape_cin<T, PM, false, MODE, true, false, false, PERSIST>), gr, bl, 0, s, a);
         return;
     }
-    if (profile) { hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a); return; }
+    if (profile) {
+        if constexpr (MODE == 2) {
+            // the lifted index and nothing else of the profile, default options, CAPE / CIN only (the product bundle's
+            // parcel passes): the LAZY instantiation (PROFILE + DEF + LEAN, see k_cape_cin)
+            const bool cc_only = !a.s.lfc_t && !a.s.el_t && !a.s.lfc_idx && !a.s.el_idx && !a.s.status;
+            if (a.prof.nlev_out == 0 && a.prof.li && a.vtc && a.pos_neg && a.log_interp && cc_only) {
+                hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, true, true, PERSIST>), gr, bl, 0, s, a);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_cape_cin<T, PM, true, MODE, false, false, false, PERSIST>), gr, bl, 0, s, a);
+        return;
+    }
     // Default-options (DEF) and CAPE/CIN-only (LEAN) specialisations: the reference's default option set as compile-time
     // constants, and -- when the caller wants neither LFC / EL temperatures nor interval indices (the bench, a multi-GPU
     // gather, the product bundle) -- no tracking of them.  The RK4 and lookup-table modes take both; the family kernels

@@ -233,6 +233,11 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // allocator (the dewpoint-input surface kernel of modes 0 / 1 lands below 128 VGPRs on its own and is allocated worse
     // when forced); tests/test_kernel_resources.py checks what comes out.
     constexpr bool TABLE = (MODE == 1), FAMILY = (MODE == 2);
+    // LAZY (family mode, PROFILE + DEF + LEAN: the host picks it when the caller wants the lifted index, NO profile rows and
+    // nothing beyond CAPE / CIN -- the product bundle's three parcel passes): the parcel's plain temperature -- three Newton
+    // steps from its virtual temperature at every level above the LCL, a quarter of a profile kernel's instructions -- is
+    // found only at the two nodes that bracket the lifted-index level.
+    constexpr bool LAZY = FAMILY && PROFILE && LEAN;
     // One LDS object with the e_s / ln table FIRST: at LDS address 0 the table base folds into the immediate offsets of the
     // ds_read instructions (the table is read ~15 times per level; behind the slots every access paid a v_mov for the base).
     // (Not for the family kernels with profile output: they sit at the 128-VGPR cap, and with the one-object layout the
@@ -335,6 +340,10 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
 
     int jout = 0;                                                           // profile row
     double li_d = qnan();                                                   // PROFILE: environment minus parcel temperature of the node before this one (lifted index)
+    // LAZY: the node before this one as it came -- its parcel temperature where the node had one (dry adiabat, LCL), else
+    // its virtual temperature, to be inverted if the next node turns out to close the bracket
+    double lz_te = qnan(), lz_tq = qnan(), lz_p = qnan();
+    int lz_known = 1;
     bool li_done = false;
     // CAPE / CIN-only kernels and the lowest valid pressure of the profile (stands in for a missing EL, pf.py:1329): recovered
     // after the walk (below) -- except for the mixed-layer parcel, whose kernels the register allocator serves better with
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     // `above` (a std::integral_constant): this node and the one before it lie strictly above the LCL (phase B)
     auto emit = [&](auto above, double P, double X, double tp, double tvp, double te, double tve, double tde, bool is_lcl) __attribute__((always_inline)) {
         if (PROFILE) {
-            if (jout < a.prof.nlev_out) {
+            if (!LAZY && jout < a.prof.nlev_out) {
                 int64_t o = jout * a.prof.ls + c * a.prof.cs;
                 bool dead = isnan_(P);                                     // NaN-coordinate rows come out all-NaN (pf.py:963, 988)
 #ifndef XP_NO_NATIVE6
@@ -377,7 +386,21 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             // coordinate; value rule of pf.py:1802-1806)
             // -- both temperatures take the same weight, so their difference is interpolated: one value of state.
             // The state lives in an LDS slot where the workgroup has one to spare (not the 1024-thread family build).
-            if (a.prof.li) {
+            if constexpr (LAZY) {
+                // (a node without a parcel temperature of its own hands in NaN for it; a NaN parcel inverts to NaN)
+                const bool known = !isnan_(tp);
+                if (!li_done && X <= a.prof.li_x + 1e-12) {
+                    const bool on = X >= a.prof.li_x - 1e-12;
+                    double off0 = 0.0, off1 = 0.0;
+                    const double tc = known ? tp : Family::temperature_from(es, P, tvp, off0);
+                    const double tb4 = lz_known ? lz_tq : Family::temperature_from(es, lz_p, lz_tq, off1);
+                    const double d_ = te - tc, dp = lz_te - tb4;
+                    const double wgt = (a.prof.li_x - sc.Xp) / (X - sc.Xp);
+                    st(a.prof.li, a.prof.f64, c, (on || dp == d_) ? d_ : dp + (d_ - dp) * wgt);
+                    li_done = true;
+                }
+                if (!isnan_(P)) { lz_te = te; lz_tq = known ? tp : tvp; lz_p = P; lz_known = known ? 1 : 0; }
+            } else if (a.prof.li) {
                 constexpr bool LI_SLOT = SLOT_FIELDS > SL_LI;
                 const double d_ = te - tp;
                 if (!li_done && X <= a.prof.li_x + 1e-12) {
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
         unsigned dist = table_dist(T_);
         if (!Q) dist = umax_(dist, table_dist(m_));
         if (PARCEL_ES && need_w) dist = umax_(dist, table_dist(tf));
-        const bool in_range = all_in_table(dist) && (!FAM_T || in_table(tf, 8.0));
+        const bool in_range = all_in_table(dist) && (!FAM_T || LAZY || in_table(tf, 8.0));
         double ep = 0.0, tve, tpf = 0.0;
         if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) {
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tf, true) : m.e;
@@ -447,14 +470,14 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             } else {
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab<LEAN && !PROFILE>(es, T_, m_, P, true);
             }
-            if (FAM_T) tpf = Family::temperature_from(es, P, tf, fam_off, true);
+            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from(es, P, tf, fam_off, true);
         } else {
             if constexpr (TRIO) tf = fam.horner(fz);
             double tq = tf;
             asm volatile("" : "+v"(tq));
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, false);
-            if (FAM_T) tpf = Family::temperature_from(es, P, tq, fam_off, false);
+            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from(es, P, tq, fam_off, false);
         }
         if constexpr (TRIO) { if (f_any_top) tf = fam.top_value(tf, X, f_top); }
         double tp, tvp;
@@ -501,7 +524,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             tvp = need_w ? tp * vf_parcel : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
             tvp = fam.at(X);
-            tp = PROFILE ? Family::temperature_from(es, P, tvp, fam_off) : !vtc ? Family::temperature_of(es, P, tvp) : tvp;
+            tp = LAZY ? qnan() : PROFILE ? Family::temperature_from(es, P, tvp, fam_off) : !vtc ? Family::temperature_of(es, P, tvp) : tvp;
         } else {
             tp = m.at(P, X, a.tb);
             tvp = need_w ? virt(tp, mix_of_e(TABLE ? es_tab(es, tp) : m.e, P)) : tp;
