@@ -38,7 +38,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_conv_columns(Conv
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.ncol) return;
     constexpr int NT = 3, NV = 3;                          // targets 850, 700, 500 hPa; variables T, Td, z
-    double at[NT] = {log(850.0), log(700.0), log(500.0)};
+    double at[NT] = {clog(850.0), clog(700.0), clog(500.0)};
     double cb[NT], ca[NT], sb[NV][NT], sa[NV][NT];
     int nb[NV][NT], na[NV][NT];
 #pragma unroll
@@ -57,7 +57,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_conv_columns(Conv
         const double Td = (double)tdr;                     // ... and that stored value is what everything downstream reads
         valid = valid && !isnan_(P) && !isnan_(Tk) && !isnan_(Q) && !isnan_(Td);
         // linear_interp in ln p (pf.py:1758-1828), exactly k_interp_levels' bookkeeping
-        const double cc = log(P);
+        const double cc = clog(P);
         double x[NV] = {Tk, Td, Z};
         if (!isnan_(cc)) {
 #pragma unroll

@@ -91,6 +91,13 @@ XP_DEV double flog(double x) {                       // fdlibm e_log.c kernel, p
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 XP_DEV double fpow(double x, double y) { return fexp(y * flog(x)); }
+// ln of a coordinate (interpolation in ln p, pf.py:1813): flog for positive finite arguments, the library's log -- with its
+// -inf / NaN results -- for everything else (a divergent branch nobody takes on sane data).  ONE function for coordinates
+// and targets, so that a level exactly on a target compares equal.
+XP_DEV double clog(double x) {
+    if (x > 0.0 && x < 1.0e300) return flog(x);
+    return log(x);
+}
 
 // ---- thermodynamics ---------------------------------------------------------------------
 // Bolton (1980): 6.112 fexp(17.67 (T-273.15)/(T-29.65)), written as fexp(17.67 - 17.67*243.5/(T-29.65))
@@ -357,16 +364,27 @@ XP_DEV double dewpoint_from_q_tab(const double *tb, double p, double t, double q
 // the w of this iteration), so a level within rounding of the LCL is a knife edge -- KAT
 // test_profile_with_lcl_in_levels puts a level exactly on it.  The level loop therefore treats a level within 1e-9
 // (relative) of p_lcl as lying ON the LCL (LCL_SNAP), which is what bitwise equality selects in the reference.
+XP_DEV double dewpoint_fast(double e) { double v = flog(e * (1.0 / 6.112)); return 273.15 + 243.5 * fdiv(v, 17.67 - v); }
 XP_DEV double es_ref(double t) { return 6.112 * exp(17.67 * (t - 273.15) / (t - 29.65)); }
 // metpy.calc.dewpoint_from_specific_humidity, MetPy 1.4.1 chain (parcel_test.py:262-266, pf.py:1889):
 // w = q/(1-q); RH = w / w_s(p, T); Td = dewpoint(RH * e_s(T)) -- library exp/log, reference operation order
-XP_DEV double dewpoint_from_q(double p, double t, double q) {
+XP_DEV double dewpoint_from_q_ref(double p, double t, double q) {
     double w = q / (1.0 - q);
     double est = es_ref(t);
     double rh = w / (EPS * est / (p - est));
     return dewpoint_of_e(rh * est);
 }
-XP_DEV double dewpoint_fast(double e) { double v = flog(e * (1.0 / 6.112)); return 273.15 + 243.5 * fdiv(v, 17.67 - v); }
+__device__ __attribute__((noinline)) double dewpoint_from_q_slow(double p, double t, double q) { return dewpoint_from_q_ref(p, t, q); }
+// The same chain in the fast fp64 forms (RH e_s(T) = w (p - e_s(T)) / eps; ~1e-15 relative, 90 instead of 250 instructions) for
+// physically sane arguments; anything else -- where IEEE infinities and the library's edge cases decide between a value and NaN --
+// takes the reference spelling above, out of line behind a ballot.
+XP_DEV double dewpoint_from_q(double p, double t, double q) {
+    const bool sane = (t > 150.0) && (t < 350.0) && (p > 1.0) && (p < 2000.0) && (q > 0.0) && (q < 0.5);
+    double e = fdiv(q, 1.0 - q) * (p - sat_vapor_pressure(t)) * (1.0 / EPS);
+    double td = (e > 0.0) ? dewpoint_fast(e) : qnan();
+    if (__builtin_amdgcn_ballot_w64(!sane) != 0ull && !sane) td = dewpoint_from_q_slow(p, t, q);
+    return td;
+}
 XP_DEV double lcl_iter(double p, double p0, double w, double t) {
     double td = dewpoint_fast(p * fdiv(w, EPS + w));
     double r = fdiv(td, t);                              // (Td / T)^(1 / kappa) = r^3.5 = r^3 sqrt(r): ~15 instructions, not exp(3.5 ln r)

@@ -946,14 +946,14 @@ void k_interp_level(View cv, View xv, int64_t nlev, int64_t ncol, const void *at
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncol) return;
     double at = ld1<T>(at_p, at_scalar ? 0 : c);
-    if (log_coords) at = log(at);
+    if (log_coords) at = clog(at);
     // coords_before = smallest coordinate >= at, coords_after = largest <= at (pf.py:1774-1775); values = mean over
     // the levels that carry exactly that coordinate, skipping NaN (pf.py:1798-1799)
     double cb = qnan(), ca = qnan(), sb = 0.0, sa = 0.0;
     int nb = 0, na = 0;
     for (int64_t k = 0; k < nlev; ++k) {
         double cc = ld<T>(cv, k, c), x = ld<T>(xv, k, c);
-        if (log_coords) cc = log(cc);
+        if (log_coords) cc = clog(cc);
         if (isnan_(cc)) continue;
         if (cc >= at) {
             if (!(cc >= cb)) { cb = cc; sb = 0.0; nb = 0; }
@@ -981,7 +981,7 @@ void k_interp_levels(View cv, InterpMany m, int64_t nlev, int64_t ncol, int log_
     int nb[NV][NT], na[NV][NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        at[j] = log_coords ? log(m.at[j]) : m.at[j];
+        at[j] = log_coords ? clog(m.at[j]) : m.at[j];
         cb[j] = ca[j] = qnan();
 #pragma unroll
         for (int v = 0; v < NV; ++v) { sb[v][j] = sa[v][j] = 0.0; nb[v][j] = na[v][j] = 0; }
@@ -990,7 +990,7 @@ void k_interp_levels(View cv, InterpMany m, int64_t nlev, int64_t ncol, int log_
         double cc = ld<T>(cv, k, c), x[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) x[v] = ld<T>(m.x[v], k, c);
-        if (log_coords) cc = log(cc);
+        if (log_coords) cc = clog(cc);
         if (isnan_(cc)) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {

@@ -180,12 +180,12 @@ void k_bound_pressure(View pv, int64_t nlev, int64_t ncol, const void *bound, vo
 // k_interp_level's rule as a device function
 template <typename T> XP_DEV double interp_column(const View &cv, const View &xv, int64_t nlev, int64_t c, double at, bool log_coords) {
 #pragma clang fp contract(off)
-    if (log_coords) at = log(at);
+    if (log_coords) at = clog(at);
     double cb = qnan(), ca = qnan(), sb = 0.0, sa = 0.0;
     int nb = 0, na = 0;
     for (int64_t k = 0; k < nlev; ++k) {
         double cc = ld<T>(cv, k, c), x = ld<T>(xv, k, c);
-        if (log_coords) cc = log(cc);
+        if (log_coords) cc = clog(cc);
         if (isnan_(cc)) continue;
         if (cc >= at) {
             if (!(cc >= cb)) { cb = cc; sb = 0.0; nb = 0; }
