@@ -675,6 +675,39 @@ struct Family {
         if (!isnan_(t)) off = tv - t;
         return t;
     }
+    // The same inversion for the level loop above the LCLs: the offset Tv - T is extrapolated from the two nodes before (it falls
+    // smoothly with height: second differences of ~0.02 K near the ground, less above), so TWO Newton steps do -- a start within
+    // 0.04 K leaves 2e-5 K after the first step (|f''/2f'| ~ 0.012 / K) and 5e-12 K after the second; a residual above 3e-5 K before
+    // the last step (the first moist node of a column, a jump in the level spacing) sends the lane through two exact steps more.
+    XP_DEV static double temperature_from2(const double *es, double p, double tv, double &off, double &offp, bool all_in_range) {
+        constexpr double c = VT_EPS * EPS;
+        double t = tv - (2.0 * off - offp), f = 0.0;
+#pragma nounroll
+        for (int it = 0; it < 2; ++it) {
+            double e = es_tab(es, t, all_in_range);
+            double rt = __builtin_amdgcn_rcp(t - 29.65), rp = frcp(p - e);
+            double de = e * (17.67 * 243.5) * (rt * rt);
+            double g = c * e * rp;
+            f = __builtin_fma(t, g, t) - tv;
+            double df = 1.0 + g + t * c * p * de * (rp * rp);
+            t = t - f * __builtin_amdgcn_rcp(df);
+        }
+        bool more = !(fabs(f) <= 3e-5);
+        if (__builtin_amdgcn_ballot_w64(more && !isnan_(tv)) != 0ull) {
+#pragma nounroll
+            for (int it = 0; it < 2; ++it) {
+                double e = es_tab(es, t);
+                double rt = frcp(t - 29.65), rp = frcp(p - e);
+                double de = e * (17.67 * 243.5) * (rt * rt);
+                double g = c * e * rp;
+                double f2 = __builtin_fma(t, g, t) - tv;
+                double df = 1.0 + g + t * c * p * de * (rp * rp);
+                t = more ? t - fdiv(f2, df) : t;
+            }
+        }
+        if (!isnan_(t)) { offp = off; off = tv - t; }
+        return t;
+    }
     XP_DEV double horner(double z) const {
         double v = c[FAM_ND];
 #pragma unroll

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
     if (FAMILY) fam.start(s_fam, es, l.p, x_lcl, l.t, l.tv);
     else m.start(es, l.p, x_lcl, l.t, TABLE, a.tb);
     double fam_off = l.tv - l.t;                                            // family profile kernels: Tv - T of the parcel at the node before (temperature_from)
+    double fam_offp = fam_off;                                              // ... and at the node before that (temperature_from2)
 
     int jout = 0;                                                           // profile row
     double li_d = qnan();                                                   // PROFILE: environment minus parcel temperature of the node before this one (lifted index)
@@ -470,14 +471,14 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             } else {
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab<LEAN && !PROFILE>(es, T_, m_, P, true);
             }
-            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from(es, P, tf, fam_off, true);
+            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from2(es, P, tf, fam_off, fam_offp, true);
         } else {
             if constexpr (TRIO) tf = fam.horner(fz);
             double tq = tf;
             asm volatile("" : "+v"(tq));
             if (need_w && !FAMILY) ep = PARCEL_ES ? es_tab(es, tq, false) : m.e;
             tve = !need_w ? T_ : Q ? virt(T_, (m_ > 0.0 && m_ < 1.0) ? fdiv(m_, 1.0 - m_) : qnan()) : virt_env_tab(es, T_, m_, P, false);
-            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from(es, P, tq, fam_off, false);
+            if (FAM_T) tpf = LAZY ? qnan() : Family::temperature_from2(es, P, tq, fam_off, fam_offp, false);
         }
         if constexpr (TRIO) { if (f_any_top) tf = fam.top_value(tf, X, f_top); }
         double tp, tvp;
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MOD
             tvp = need_w ? tp * vf_parcel : tp;
         } else if (FAMILY) {                                               // the table holds the virtual temperature
             tvp = fam.at(X);
+            if (PROFILE && !LAZY) fam_offp = fam_off;
             tp = LAZY ? qnan() : PROFILE ? Family::temperature_from(es, P, tvp, fam_off) : !vtc ? Family::temperature_of(es, P, tvp) : tvp;
         } else {
             tp = m.at(P, X, a.tb);
