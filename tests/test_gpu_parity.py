@@ -265,6 +265,12 @@ def test_lifted_index_only_kernels_of_family_mode():
     pb, tb, tdb = synth.columns(nlev=33, ncol=(3 << 18) + 77, seed=23, nan_fraction=0.05, dtype=np.float32)   # persistent wavefronts
     for kw in ({}, {'parcel': 'most_unstable', 'depth': 300}):
         assert check(pb, tb, tdb, 2e-4, **kw) > 500000
+    # columns the family table cannot serve (adiabats warmer than its 312 K edge) are redone by the RK4 kernel: the index comes from there
+    th, tdh = t.copy(), td.copy()
+    th[:, ::7] += 22.0; tdh[:, ::7] += 24.0
+    tdh = np.minimum(tdh, th)
+    assert check(p, th, tdh, 1e-9) > 1500
+    assert check(p, th, tdh, 1e-9, parcel='most_unstable', depth=300) > 1500
     # against the NumPy oracle (RK4 adiabat: the family table is within 1e-6 K of it)
     from oracle import parcel_oracle as po
     got = xa.cape_cin_columns(p, t, td, parcel='mixed_layer', depth=100, moist='family', lifted_index_at=500.0, want=('cape', 'cin'))['lifted_index']
