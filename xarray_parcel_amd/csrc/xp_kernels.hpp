@@ -226,6 +226,7 @@ template <typename T, bool HUM> XP_DEV Parcel select_ml(const CapeArgs &a, int64
 // (xp_cape_tu.hip has the dispatch rule and why).
 // LEAN (with DEF): the caller wants neither LFC / EL temperatures nor interval indices (the bench, the gather of a
 // multi-GPU run): they are not tracked, see Scan::node.
+// PROFILE + DEF + LEAN (family mode only): the lifted index of the profile and none of its rows -- `LAZY` below.
 template <typename T, int PMODE, bool PROFILE, int MODE, bool HUM, bool DEF, bool LEAN, bool PERSIST>
 __global__ __launch_bounds__(XP_CAPE_THREADS, (XP_CAPE_THREADS >= 1024 ? 4 : MODE == 2 ? 3 : PROFILE ? 4 : (PMODE == PM_SURFACE ? (HUM ? 3 : 1) : 4))) void k_cape_cin(CapeArgs a) {
     // Occupancy: four wavefronts per SIMD everywhere -- the family translation units through their 1024-thread workgroups
