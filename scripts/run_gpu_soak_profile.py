@@ -1,0 +1,47 @@
+"""Profile-output soak (family mode): the six profile arrays of xp_cape_cin against the C oracle's, seeds x level counts x parcels x dtypes;
+NaN patterns identical, values within 1e-9 K (fp64) / fp32 rounding; and the lifted-index-only kernels against the index of the written profile.
+Columns with a model level within 2e-9 (relative) of the LCL are counted and left out: the kernels treat such a level as ON the LCL (xp_device.hpp,
+LCL_SNAP: their LCL and the reference's agree to ~1e-13, not to the last bit, and the parcel's virtual temperature jumps by ~0.01-0.04 K there),
+the oracle takes the side its own rounding gives.
+run_gpu_soak_profile.py [ncol] [nseeds]"""
+import sys, itertools, time
+sys.path.insert(0, '.')
+import numpy as np
+from oracle import c_oracle as co
+from xarray_parcel_amd import numpy_api as xa, synth
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+seeds = range(300, 300 + (int(sys.argv[2]) if len(sys.argv) > 2 else 3))
+xa.set_family_table(co.family_table())
+bad = n = 0; worst = 0.0; t0 = time.time(); knife = 0
+for seed, nlev, (parcel, kw), dtype in itertools.product(seeds, (9, 33, 64, 100), (('surface', {}), ('most_unstable', {'depth': 300}), ('mixed_layer', {'depth': 100})),
+                                                       (np.float64, np.float32)):
+    p, t, td = synth.columns(nlev=nlev, ncol=ncol, seed=seed * 11 + nlev, nan_fraction=0.06, dtype=dtype)
+    got = xa.cape_cin_columns(p, t, td, parcel=parcel, moist='family', want_profile=True, **kw)
+    ref = co.cape_cin_grid(p, t, td, parcel=parcel, moist='family', want_profile=True, **kw)
+    tol = 1e-9 if dtype == np.float64 else 4e-5
+    ok = True
+    with np.errstate(invalid='ignore'):
+        lp = np.asarray(ref['lcl_pressure'], dtype=np.float64)
+        rel = np.abs(p.astype(np.float64) - lp[None, :]) / lp[None, :]
+        rel[~(rel > 0.0)] = np.inf                                          # (a level exactly ON the LCL -- a saturated parcel -- is no knife edge)
+        near = rel.min(axis=0) < 2e-9
+    keep = ~near
+    knife += int(near.sum())
+    for k in ('pressure', 'temperature', 'virtual_temperature', 'environment_temperature', 'environment_virtual_temperature', 'environment_dewpoint'):
+        a, b = np.asarray(got['profile'][k], dtype=np.float64)[:, keep], np.asarray(ref['profile'][k], dtype=np.float64)[:, keep]
+        m = min(a.shape[0], b.shape[0])
+        if not np.array_equal(np.isnan(a[:m]), np.isnan(b[:m])) or not np.all(np.isnan(a[m:])) or not np.all(np.isnan(b[m:])):
+            # saturated-tie columns may differ by an LFC decision, never by a profile row
+            ok = False; print('NaN pattern', seed, nlev, parcel, dtype.__name__, k); continue
+        v = ~np.isnan(b[:m])
+        d = float(np.max(np.abs(a[:m][v] - b[:m][v]) / np.maximum(1.0, np.abs(b[:m][v]) / 300.0))) if v.any() else 0.0
+        worst = max(worst, d) if dtype == np.float64 else worst
+        if d > tol: ok = False; print('value', seed, nlev, parcel, dtype.__name__, k, d)
+    li = xa.cape_cin_columns(p, t, td, parcel=parcel, moist='family', lifted_index_at=500.0, want=('cape', 'cin'), **kw)['lifted_index']
+    lr = xa.lifted_index(got['profile'])
+    v = ~np.isnan(lr)
+    if not np.array_equal(np.isnan(li), np.isnan(lr)) or (v.any() and float(np.max(np.abs(li[v] - lr[v]))) > (1e-9 if dtype == np.float64 else 2e-4)):
+        ok = False; print('lifted index', seed, nlev, parcel, dtype.__name__)
+    n += 1; bad += (not ok)
+print(f'PROFILE SOAK {n} combinations x {ncol} columns: {bad} mismatching combinations; worst fp64 deviation {worst:.2e} K; {knife} columns with a level within 2e-9 of (not on) the LCL left out; {time.time() - t0:.0f} s')
+sys.exit(1 if bad else 0)
