@@ -109,14 +109,14 @@ def cpu_baseline(seed, nlev, sample_cols, parcel, moist):
     omode = 'family' if moist == 'family' else 'rk4'        # (table mode: the oracle's tables are not built here; RK4 stands in)
     c_oracle.cape_cin_grid(p[:, :2048], t[:, :2048], td[:, :2048], moist=omode, parcel=parcel)   # warm up threads, build tables
     times = []
-    for _ in range(5):                                   # protocol of parcel_test.py:31-35: wall clock, repeats, median
+    for _ in range(9):                                   # protocol of parcel_test.py:31-35: wall clock, repeats, median (~10-12 s of CPU work in all)
         t0 = time.perf_counter()
         c_oracle.cape_cin_grid(p, t, td, moist=omode, parcel=parcel)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     return {'value': sample_cols / dt, 'unit': 'column-profiles/s', 'cores': c_oracle.max_threads(), 'kind': 'port',
             'sample': f'{sample_cols} columns x {nlev} levels of the same synthetic workload ({parcel} parcel), '
-                      f'oracle/c/xp_oracle.c (OpenMP, moist mode {omode}), median of 5 runs, {dt:.2f} s each'}
+                      f'oracle/c/xp_oracle.c (OpenMP, moist mode {omode}), median of 9 runs, {dt:.2f} s each'}
 
 
 def _event_ms(fn, steps=5, warmup=2):
